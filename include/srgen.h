@@ -1,0 +1,129 @@
+/*
+ * srgen.h -- C ABI of libsrgen.so: the MI355X (gfx950) SRGAN-generator forward.
+ *
+ * The reference (Charan6924/SuperResolution) has no FFI/plugin interface of its own: its
+ * boundary for this path is the Python torch.nn.Module API of `Generator`
+ * (/root/reference/Generator.py:45-80), exercised at train.py:37,65,92,149,167 (calls),
+ * train.py:247,250 (construction / .to(device)) and train.py:119,214,268 (state_dict /
+ * load_state_dict).  Each entry point below states which part of that Python surface it
+ * replaces; superresolution_amd/generator.py binds them with ctypes.
+ *
+ * Conventions
+ *   - every function returns 0 on success and a negative SRGEN_E_* code on failure; nothing
+ *     throws or aborts across the ABI; srgen_last_error() gives the message (thread-local).
+ *   - plain pointers and sizes only: device pointers are HIP device addresses on the
+ *     handle's device, host pointers are ordinary host memory; `stream` is a hipStream_t
+ *     passed as void* (NULL = the default stream).
+ *   - srgen_forward* allocate nothing and never synchronise: input, output and workspace
+ *     are the caller's (PyTorch: torch.empty on the current device); all work is enqueued
+ *     on `stream`.  Device memory owned by the library is only the packed weights, which
+ *     srgen_commit_weights (re)allocates.
+ *   - a handle is bound to the device that was current at srgen_create; it is not safe to
+ *     call concurrently on ONE handle, different handles are independent.
+ *   - tensors cross the boundary in the reference's layout: NCHW, contiguous.
+ */
+#ifndef SRGEN_H
+#define SRGEN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SRGEN_ABI_VERSION 1
+
+#if defined(__GNUC__)
+#define SRGEN_API __attribute__((visibility("default")))
+#else
+#define SRGEN_API
+#endif
+
+enum {
+    SRGEN_OK = 0,
+    SRGEN_E_INVALID = -1,      /* bad argument (NULL, shape, dtype, alignment)          */
+    SRGEN_E_KEY = -2,          /* unknown / missing / wrongly sized state_dict entry    */
+    SRGEN_E_STATE = -3,        /* call order (forward before commit, ...)               */
+    SRGEN_E_HIP = -4,          /* a HIP runtime call failed                             */
+    SRGEN_E_WORKSPACE = -5,    /* workspace too small or misaligned                     */
+    SRGEN_E_UNSUPPORTED = -6   /* configuration this build has no kernel for            */
+};
+
+/* arithmetic / storage type of the activations between layers (accumulation is fp32) */
+enum { SRGEN_F32 = 0, SRGEN_BF16 = 1 };
+
+typedef struct srgen_handle srgen_handle;
+
+/* Generator(num_blocks=16, in_ch=3, base_ch=96) -- Generator.py:46.  ChannelAttention is
+ * inserted after residual blocks 7 and 15 (Generator.py:57).  This build has kernels for
+ * in_ch == 3, base_ch == 96, num_blocks in [1, 64]; anything else -> SRGEN_E_UNSUPPORTED. */
+typedef struct srgen_config {
+    int32_t num_blocks;
+    int32_t in_ch;
+    int32_t base_ch;
+} srgen_config;
+
+/* Replaces: Generator.__init__ + .to(device) (Generator.py:45-72, train.py:247). */
+SRGEN_API int srgen_create(const srgen_config* cfg, srgen_handle** out);
+SRGEN_API int srgen_destroy(srgen_handle* h);
+
+/* Replaces: Module.load_state_dict (train.py:268).  Feed every floating-point entry of the
+ * reference state_dict by its exact key ("input.0.weight", "blocks.3.block.1.running_var",
+ * "blocks.8.fc.2.bias", ...), fp32, contiguous, host memory; `numel` must match the shape
+ * Generator.py implies.  "*.num_batches_tracked" keys are accepted and ignored.  Then
+ * srgen_commit_weights folds eval-mode BatchNorm (Generator.py:35,38,63; eps 1e-5) and the
+ * 0.1 residual scale (Generator.py:42) into the conv weights in fp64, packs them for the
+ * MFMA kernels (fp32 and bf16 images) and uploads them.  Missing keys -> SRGEN_E_KEY.
+ * Re-callable: a later set/commit replaces the weights (ordered after prior work on
+ * `stream`). */
+SRGEN_API int srgen_set_tensor(srgen_handle* h, const char* key, const float* host_data, size_t numel);
+SRGEN_API int srgen_commit_weights(srgen_handle* h, void* stream);
+
+/* Bytes of caller-provided device workspace srgen_forward needs for a batch of n images.
+ * 256-byte alignment required. */
+SRGEN_API int srgen_workspace_bytes(const srgen_handle* h, int n, int dtype, size_t* bytes);
+
+/* Replaces: Generator.forward in eval mode (Generator.py:74-80; train.py:37,65).
+ *   x  : device, (n, 3, 64, 64)   NCHW contiguous, fp32 (SRGEN_F32) or bf16 (SRGEN_BF16)
+ *   y  : device, (n, 3, 125, 125) NCHW contiguous, same dtype as x.  The reference returns
+ *        the [:125,:125] crop of a 128x128 map as a view (Generator.py:80); here the crop is
+ *        folded into the last store and y is dense.  Not clamped (callers clamp, train.py:38).
+ */
+SRGEN_API int srgen_forward(srgen_handle* h, const void* x, void* y, void* workspace,
+                  size_t workspace_bytes, int n, int dtype, void* stream);
+
+/* Layer taps for parity tests: same as srgen_forward, and additionally copies intermediate
+ * activations out as NCHW fp32.  taps[i] is a device pointer or NULL (skip):
+ *   0 stem (n,96,64,64)   1 block0   2 block7   3 ca8   4 block16   5 ca17   6 skip (x1+x3)
+ *   7 upsample (n,96,128,128)   8 output1 (n,96,128,128)
+ *   9 ca8_scale (n,96)   10 ca17_scale (n,96)
+ * (module outputs of Generator.py:75, blocks[0], [7], [8], [16], [17], :78, :12, output[1],
+ *  and the sigmoid outputs of :19-24.) */
+#define SRGEN_NUM_TAPS 11
+SRGEN_API int srgen_forward_taps(srgen_handle* h, const void* x, void* y, void* workspace,
+                       size_t workspace_bytes, int n, int dtype, void* const* taps,
+                       void* stream);
+
+/* Optional op named by BASELINE.json's north_star, NOT on the reference's forward path
+ * (Generator.py:80 crops; only README.md:52 mentions bilinear): coalesced bilinear resize
+ * with torch.nn.functional.interpolate(mode='bilinear', align_corners=False) semantics.
+ *   x: device (planes, h, w) fp32   y: device (planes, oh, ow) fp32 */
+SRGEN_API int srgen_bilinear_resize(const float* x, float* y, int planes, int h, int w, int oh, int ow,
+                          void* stream);
+
+/* Replaces: utils.psnr / utils.ssim / nn.L1Loss as called per batch by validate()
+ * (train.py:66-68; utils.py:5-41).  sr, hr: device (n, 3, hgt, wid) NCHW fp32.
+ * out3: device, 3 floats {psnr, ssim, l1} for the whole batch -- stays on the device so the
+ * caller can accumulate without a .item() sync.  scratch: device, srgen_metrics_scratch_bytes(). */
+SRGEN_API int srgen_metrics_scratch_bytes(int n, int c, int hgt, int wid, size_t* bytes);
+SRGEN_API int srgen_metrics(const float* sr, const float* hr, int n, int c, int hgt, int wid,
+                  float* out3, void* scratch, size_t scratch_bytes, void* stream);
+
+SRGEN_API const char* srgen_last_error(void);
+SRGEN_API int srgen_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SRGEN_H */

@@ -1,0 +1,78 @@
+"""ctypes binding of libsrgen.so (include/srgen.h).  The HIP library is the product path:
+if it is missing this module raises -- there is no CPU or eager-PyTorch fallback."""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libsrgen.so")
+
+SRGEN_F32, SRGEN_BF16 = 0, 1
+NUM_TAPS = 11
+TAP_NAMES = ("stem", "block0", "block7", "ca8", "block16", "ca17", "skip", "upsample", "output1",
+             "ca8_scale", "ca17_scale")
+
+_lib = None
+
+
+class SrgenError(RuntimeError):
+    pass
+
+
+class srgen_config(ctypes.Structure):
+    _fields_ = [("num_blocks", ctypes.c_int32), ("in_ch", ctypes.c_int32), ("base_ch", ctypes.c_int32)]
+
+
+def build(force: bool = False, jobs: int = 4) -> str:
+    """Compile the gfx950 kernels + C ABI in-tree (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, f"-j{jobs}", "libsrgen.so"]
+    if force:
+        cmd.insert(1, "-B")
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SrgenError(
+            f"{LIB_PATH} is missing: the HIP extension is not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C superresolution_amd/csrc`). "
+            "There is no fallback path.")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+    L.srgen_abi_version.restype = i
+    L.srgen_last_error.restype = ctypes.c_char_p
+    L.srgen_create.argtypes = [ctypes.POINTER(srgen_config), ctypes.POINTER(vp)]
+    L.srgen_destroy.argtypes = [vp]
+    L.srgen_set_tensor.argtypes = [vp, ctypes.c_char_p, vp, sz]
+    L.srgen_commit_weights.argtypes = [vp, vp]
+    L.srgen_workspace_bytes.argtypes = [vp, i, i, ctypes.POINTER(sz)]
+    L.srgen_forward.argtypes = [vp, vp, vp, vp, sz, i, i, vp]
+    L.srgen_forward_taps.argtypes = [vp, vp, vp, vp, sz, i, i, ctypes.POINTER(vp), vp]
+    L.srgen_bilinear_resize.argtypes = [vp, vp, i, i, i, i, i, vp]
+    L.srgen_metrics_scratch_bytes.argtypes = [i, i, i, i, ctypes.POINTER(sz)]
+    L.srgen_metrics.argtypes = [vp, vp, i, i, i, i, vp, vp, sz, vp]
+    for name in ("srgen_create", "srgen_destroy", "srgen_set_tensor", "srgen_commit_weights",
+                 "srgen_workspace_bytes", "srgen_forward", "srgen_forward_taps", "srgen_bilinear_resize",
+                 "srgen_metrics_scratch_bytes", "srgen_metrics"):
+        getattr(L, name).restype = i
+    if L.srgen_abi_version() != 1:
+        raise SrgenError(f"libsrgen.so ABI version {L.srgen_abi_version()} != 1; rebuild it")
+    _lib = L
+    return L
+
+
+def check(rc: int) -> None:
+    """Map a negative srgen return code to a Python exception carrying srgen_last_error()."""
+    if rc == 0:
+        return
+    msg = lib().srgen_last_error().decode("utf-8", "replace")
+    if rc == -2:                       # SRGEN_E_KEY: same exception type load_state_dict raises
+        raise RuntimeError(f"Error(s) in loading state_dict for Generator: {msg}")
+    raise SrgenError(f"libsrgen error {rc}: {msg}")

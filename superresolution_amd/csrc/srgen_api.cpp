@@ -1,0 +1,560 @@
+// srgen_api.cpp -- the C ABI of include/srgen.h: handle, state_dict intake, BatchNorm/0.1
+// folding (fp64), weight packing for the MFMA kernels, and the forward plan.
+//
+// Reference semantics followed here (file:line into /root/reference):
+//   module tree / key names ......... Generator.py:45-72
+//   ResBlock  x + 0.1*block(x) ...... Generator.py:41-42   (0.1 folded into conv2's w, b)
+//   BatchNorm2d eval, eps 1e-5 ...... Generator.py:35,38,63 (folded into the preceding conv)
+//   ChannelAttention after blocks 7, 15 .. Generator.py:57-58
+//   forward order ................... Generator.py:74-80
+#include "../../include/srgen.h"
+#include "srgen_internal.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace srgen;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail(SRGEN_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                               \
+    } while (0)
+
+inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+inline uint16_t f32_to_bf16(float f)
+{
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+struct ConvDev {           // offsets (bytes) into the device weight blob
+    size_t w_f32 = 0, w_bf16 = 0, bias = 0, slope = 0;
+    bool has_slope = false;
+    int cout_blocks = 1;
+};
+struct CaDev { size_t w1 = 0, b1 = 0, w2 = 0, b2 = 0; };
+
+}  // namespace
+
+struct srgen_handle {
+    srgen_config cfg;
+    int device = 0;
+    std::map<std::string, std::vector<float>> tensors;
+    bool committed = false;
+    char* blob = nullptr;          // device
+    size_t blob_bytes = 0;
+    ConvDev stem, mid, up, out0, head;
+    std::vector<ConvDev> conv1, conv2;   // per residual block
+    CaDev ca[2];
+};
+
+namespace {
+
+// ---- expected state_dict entries -------------------------------------------------------
+struct KeySpec { std::string key; size_t numel; };
+
+void add_conv(std::vector<KeySpec>& v, const std::string& p, int co, int ci, int k)
+{
+    v.push_back({p + ".weight", (size_t)co * ci * k * k});
+    v.push_back({p + ".bias", (size_t)co});
+}
+void add_bn(std::vector<KeySpec>& v, const std::string& p, int c)
+{
+    for (const char* leaf : {".weight", ".bias", ".running_mean", ".running_var"})
+        v.push_back({p + leaf, (size_t)c});
+}
+// Sequential index of residual block i (ChannelAttention sits after blocks 7 and 15).
+int seq_index(int i) { return i + (i > 7 ? 1 : 0) + (i > 15 ? 1 : 0); }
+
+std::vector<KeySpec> expected_keys(const srgen_config& c)
+{
+    std::vector<KeySpec> v;
+    const int C = c.base_ch;
+    add_conv(v, "input.0", C, c.in_ch, 9);
+    v.push_back({"input.1.weight", 1});
+    for (int i = 0; i < c.num_blocks; ++i) {
+        const std::string p = "blocks." + std::to_string(seq_index(i)) + ".block";
+        add_conv(v, p + ".0", C, C, 3);
+        add_bn(v, p + ".1", C);
+        v.push_back({p + ".2.weight", (size_t)C});
+        add_conv(v, p + ".3", C, C, 3);
+        add_bn(v, p + ".4", C);
+        if (i == 7 || i == 15) {
+            const std::string q = "blocks." + std::to_string(seq_index(i) + 1) + ".fc";
+            add_conv(v, q + ".0", C / 8, C, 1);
+            add_conv(v, q + ".2", C, C / 8, 1);
+        }
+    }
+    add_conv(v, "mid.0", C, C, 3);
+    add_bn(v, "mid.1", C);
+    add_conv(v, "upsample.conv", 4 * C, C, 3);
+    v.push_back({"upsample.act.weight", 1});
+    add_conv(v, "output.0", C, C, 3);
+    v.push_back({"output.1.weight", 1});
+    add_conv(v, "output.2", c.in_ch, C, 9);
+    return v;
+}
+
+// ---- folding ---------------------------------------------------------------------------
+// conv (cout,cin,k,k) + optional eval BN + optional scalar: w' = w*s*g, b' = ((b-mu)*s+beta)*g
+// with s = gamma/sqrt(var+eps), computed in fp64 and rounded once to fp32.
+struct Folded { std::vector<float> w, b; int cout, cin, k; };
+
+Folded fold(const srgen_handle* h, const std::string& conv, const std::string& bn, double g, int cout,
+            int cin, int k)
+{
+    const auto& w = h->tensors.at(conv + ".weight");
+    const auto& b = h->tensors.at(conv + ".bias");
+    Folded f;
+    f.cout = cout; f.cin = cin; f.k = k;
+    f.w.resize(w.size());
+    f.b.resize(cout);
+    const size_t per = (size_t)cin * k * k;
+    for (int co = 0; co < cout; ++co) {
+        double s = 1.0, mu = 0.0, beta = 0.0;
+        if (!bn.empty()) {
+            const double gamma = h->tensors.at(bn + ".weight")[co];
+            const double var = h->tensors.at(bn + ".running_var")[co];
+            mu = h->tensors.at(bn + ".running_mean")[co];
+            beta = h->tensors.at(bn + ".bias")[co];
+            s = gamma / std::sqrt(var + 1e-5);
+        }
+        for (size_t i = 0; i < per; ++i) f.w[co * per + i] = (float)((double)w[co * per + i] * s * g);
+        f.b[co] = (float)((((double)b[co] - mu) * s + beta) * g);
+    }
+    return f;
+}
+
+// ---- device blob builder ---------------------------------------------------------------
+struct Blob {
+    std::vector<char> bytes;
+    size_t reserve(size_t n)
+    {
+        const size_t off = align256(bytes.size());
+        bytes.resize(off + n, 0);
+        return off;
+    }
+    size_t put_f32(const std::vector<float>& v)
+    {
+        const size_t off = reserve(v.size() * 4);
+        memcpy(bytes.data() + off, v.data(), v.size() * 4);
+        return off;
+    }
+    size_t put_u16(const std::vector<uint16_t>& v)
+    {
+        const size_t off = reserve(v.size() * 2);
+        memcpy(bytes.data() + off, v.data(), v.size() * 2);
+        return off;
+    }
+};
+
+// 3x3, cin = 96, cout = 96*cb.  `perm` maps packed output channel -> original output channel.
+// fp32 image: float4 units [cb][tap][ci/4][co 96] (4 consecutive ci per unit).
+std::vector<float> pack3x3_f32(const Folded& f, int cb, const std::vector<int>& perm)
+{
+    std::vector<float> p((size_t)cb * kConv3x3F32Floats);
+    for (int b = 0; b < cb; ++b)
+        for (int tap = 0; tap < 9; ++tap)
+            for (int ci = 0; ci < 96; ++ci)
+                for (int co = 0; co < 96; ++co) {
+                    const int oc = perm[b * 96 + co];
+                    const float v = f.w[(((size_t)oc * 96 + ci) * 3 + tap / 3) * 3 + tap % 3];
+                    p[((((size_t)b * 9 + tap) * 24 + ci / 4) * 96 + co) * 4 + (ci & 3)] = v;
+                }
+    return p;
+}
+
+// bf16 image: 8-element units [cb][tap][ci/8][co 96] (8 consecutive ci per unit = one
+// 32x32x16 B fragment element group).
+std::vector<uint16_t> pack3x3_bf16(const Folded& f, int cb, const std::vector<int>& perm)
+{
+    std::vector<uint16_t> p((size_t)cb * 9 * 96 * 96);
+    for (int b = 0; b < cb; ++b)
+        for (int tap = 0; tap < 9; ++tap)
+            for (int ci = 0; ci < 96; ++ci)
+                for (int co = 0; co < 96; ++co) {
+                    const int oc = perm[b * 96 + co];
+                    const float v = f.w[(((size_t)oc * 96 + ci) * 3 + tap / 3) * 3 + tap % 3];
+                    p[((((size_t)b * 9 + tap) * 12 + ci / 8) * 96 + co) * 8 + (ci & 7)] = f32_to_bf16(v);
+                }
+    return p;
+}
+
+// stem 9x9, cin 3: [k 256][co 96], k = ky*28 + kx*3 + ci.
+std::vector<float> pack_stem_f32(const Folded& f)
+{
+    std::vector<float> p(kStemF32Floats, 0.f);
+    for (int co = 0; co < 96; ++co)
+        for (int ci = 0; ci < 3; ++ci)
+            for (int ky = 0; ky < 9; ++ky)
+                for (int kx = 0; kx < 9; ++kx)
+                    p[(size_t)(ky * 28 + kx * 3 + ci) * 96 + co] = f.w[(((size_t)co * 3 + ci) * 9 + ky) * 9 + kx];
+    return p;
+}
+
+// head 9x9, cout 3: float2 units [ky][c8][u][h][n 32]; ci = 8*c8 + 2*(2u+h) + e; n = kx*3+co.
+std::vector<float> pack_head_f32(const Folded& f)
+{
+    std::vector<float> p(kHeadF32Floats, 0.f);
+    for (int ky = 0; ky < 9; ++ky)
+        for (int c8 = 0; c8 < 12; ++c8)
+            for (int u = 0; u < 2; ++u)
+                for (int hh = 0; hh < 2; ++hh)
+                    for (int kx = 0; kx < 9; ++kx)
+                        for (int co = 0; co < 3; ++co)
+                            for (int e = 0; e < 2; ++e) {
+                                const int ci = 8 * c8 + 2 * (2 * u + hh) + e;
+                                const int n = kx * 3 + co;
+                                p[(((((size_t)ky * 12 + c8) * 2 + u) * 2 + hh) * 32 + n) * 2 + e] =
+                                    f.w[(((size_t)co * 96 + ci) * 9 + ky) * 9 + kx];
+                            }
+    return p;
+}
+
+std::vector<int> identity_perm(int n)
+{
+    std::vector<int> v(n);
+    for (int i = 0; i < n; ++i) v[i] = i;
+    return v;
+}
+
+ConvDev emit_conv3x3(Blob& blob, const Folded& f, int cb, const std::vector<int>& perm,
+                     const std::vector<float>* slope_src, bool slope_scalar)
+{
+    ConvDev d;
+    d.cout_blocks = cb;
+    d.w_f32 = blob.put_f32(pack3x3_f32(f, cb, perm));
+    d.w_bf16 = blob.put_u16(pack3x3_bf16(f, cb, perm));
+    std::vector<float> bias((size_t)cb * 96), slope((size_t)cb * 96, 1.f);
+    for (int i = 0; i < cb * 96; ++i) {
+        bias[i] = f.b[perm[i]];
+        if (slope_src) slope[i] = slope_scalar ? (*slope_src)[0] : (*slope_src)[perm[i]];
+    }
+    d.bias = blob.put_f32(bias);
+    d.has_slope = slope_src != nullptr;
+    if (d.has_slope) d.slope = blob.put_f32(slope);
+    return d;
+}
+
+struct Workspace {
+    size_t x1, a, b, t, u, v, pool, scale[2], total;
+};
+
+Workspace plan_workspace(int n, int dtype)
+{
+    const size_t e = dtype == SRGEN_BF16 ? 2 : 4;
+    const size_t lr = align256((size_t)n * kLR * kLR * kC * e);
+    const size_t hr = align256((size_t)n * kHR * kHR * kC * e);
+    Workspace w;
+    // [x1 | a | b | t] are dead once the upsample conv has run; output[0]'s result (v) re-uses
+    // that region (4 * lr >= hr since 4*64*64 == 128*128).
+    w.x1 = 0; w.a = lr; w.b = 2 * lr; w.t = 3 * lr;
+    w.v = 0;
+    size_t off = 4 * lr > hr ? 4 * lr : hr;
+    w.u = off; off += hr;
+    w.pool = off; off += align256((size_t)n * 16 * kC * 4);
+    w.scale[0] = off; off += align256((size_t)n * kC * 4);
+    w.scale[1] = off; off += align256((size_t)n * kC * 4);
+    w.total = off;
+    return w;
+}
+
+int check_cfg(const srgen_config* c)
+{
+    if (!c) return fail(SRGEN_E_INVALID, "config is NULL");
+    if (c->in_ch != 3 || c->base_ch != 96)
+        return fail(SRGEN_E_UNSUPPORTED, "this build has kernels for in_ch=3, base_ch=96 only (got %d, %d)",
+                    c->in_ch, c->base_ch);
+    if (c->num_blocks < 1 || c->num_blocks > 64)
+        return fail(SRGEN_E_UNSUPPORTED, "num_blocks %d outside [1, 64]", c->num_blocks);
+    return SRGEN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int srgen_abi_version(void) { return SRGEN_ABI_VERSION; }
+const char* srgen_last_error(void) { return g_err; }
+
+int srgen_create(const srgen_config* cfg, srgen_handle** out)
+{
+    if (!out) return fail(SRGEN_E_INVALID, "out is NULL");
+    *out = nullptr;
+    if (int rc = check_cfg(cfg)) return rc;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    srgen_handle* h = new (std::nothrow) srgen_handle();
+    if (!h) return fail(SRGEN_E_INVALID, "out of host memory");
+    h->cfg = *cfg;
+    h->device = dev;
+    *out = h;
+    return SRGEN_OK;
+}
+
+int srgen_destroy(srgen_handle* h)
+{
+    if (!h) return SRGEN_OK;
+    if (h->blob) (void)hipFree(h->blob);
+    delete h;
+    return SRGEN_OK;
+}
+
+int srgen_set_tensor(srgen_handle* h, const char* key, const float* host_data, size_t numel)
+{
+    if (!h || !key) return fail(SRGEN_E_INVALID, "handle or key is NULL");
+    const std::string k(key);
+    const std::string suffix = ".num_batches_tracked";
+    if (k.size() > suffix.size() && k.compare(k.size() - suffix.size(), suffix.size(), suffix) == 0)
+        return SRGEN_OK;                              // integer bookkeeping, unused in eval
+    if (!host_data) return fail(SRGEN_E_INVALID, "data for '%s' is NULL", key);
+    for (const KeySpec& s : expected_keys(h->cfg))
+        if (s.key == k) {
+            if (s.numel != numel)
+                return fail(SRGEN_E_KEY, "size mismatch for %s: expected %zu elements, got %zu", key,
+                            s.numel, numel);
+            h->tensors[k].assign(host_data, host_data + numel);
+            h->committed = false;
+            return SRGEN_OK;
+        }
+    return fail(SRGEN_E_KEY, "unexpected key in state_dict: %s", key);
+}
+
+int srgen_commit_weights(srgen_handle* h, void* stream)
+{
+    if (!h) return fail(SRGEN_E_INVALID, "handle is NULL");
+    std::string missing;
+    int nmiss = 0;
+    for (const KeySpec& s : expected_keys(h->cfg))
+        if (!h->tensors.count(s.key)) {
+            if (nmiss++ < 4) missing += (missing.empty() ? "" : ", ") + s.key;
+        }
+    if (nmiss) return fail(SRGEN_E_KEY, "missing %d key(s) in state_dict: %s%s", nmiss, missing.c_str(),
+                           nmiss > 4 ? ", ..." : "");
+
+    Blob blob;
+    const std::vector<int> id96 = identity_perm(96);
+    {   // stem: conv 9x9 + scalar PReLU                                   Generator.py:49-52
+        Folded f = fold(h, "input.0", "", 1.0, 96, 3, 9);
+        h->stem = ConvDev();
+        h->stem.w_f32 = blob.put_f32(pack_stem_f32(f));
+        h->stem.w_bf16 = h->stem.w_f32;     // the stem runs its 0.66 % of the FLOPs in fp32
+        h->stem.bias = blob.put_f32(f.b);
+        h->stem.slope = blob.put_f32(std::vector<float>(96, h->tensors.at("input.1.weight")[0]));
+        h->stem.has_slope = true;
+    }
+    h->conv1.clear();
+    h->conv2.clear();
+    for (int i = 0; i < h->cfg.num_blocks; ++i) {                        // Generator.py:30-42
+        const std::string p = "blocks." + std::to_string(seq_index(i)) + ".block";
+        Folded f1 = fold(h, p + ".0", p + ".1", 1.0, 96, 96, 3);
+        h->conv1.push_back(emit_conv3x3(blob, f1, 1, id96, &h->tensors.at(p + ".2.weight"), false));
+        Folded f2 = fold(h, p + ".3", p + ".4", 0.1, 96, 96, 3);
+        h->conv2.push_back(emit_conv3x3(blob, f2, 1, id96, nullptr, false));
+        if (i == 7 || i == 15) {                                          // Generator.py:15-27
+            const std::string q = "blocks." + std::to_string(seq_index(i) + 1) + ".fc";
+            CaDev& c = h->ca[i == 7 ? 0 : 1];
+            c.w1 = blob.put_f32(h->tensors.at(q + ".0.weight"));
+            c.b1 = blob.put_f32(h->tensors.at(q + ".0.bias"));
+            c.w2 = blob.put_f32(h->tensors.at(q + ".2.weight"));
+            c.b2 = blob.put_f32(h->tensors.at(q + ".2.bias"));
+        }
+    }
+    {   // mid: conv + BN                                                  Generator.py:61-64
+        Folded f = fold(h, "mid.0", "mid.1", 1.0, 96, 96, 3);
+        h->mid = emit_conv3x3(blob, f, 1, id96, nullptr, false);
+    }
+    {   // upsample conv 96 -> 384; PixelShuffle(2): out[c][2y+i][2x+j] = conv[4c+2i+j][y][x]
+        // (Generator.py:7-8), so packed block b = 2i+j holds original channels 4c+b.
+        Folded f = fold(h, "upsample.conv", "", 1.0, 384, 96, 3);
+        std::vector<int> perm(384);
+        for (int b = 0; b < 4; ++b)
+            for (int c = 0; c < 96; ++c) perm[b * 96 + c] = 4 * c + b;
+        h->up = emit_conv3x3(blob, f, 4, perm, &h->tensors.at("upsample.act.weight"), true);
+    }
+    {   // output[0] + scalar PReLU                                        Generator.py:69-70
+        Folded f = fold(h, "output.0", "", 1.0, 96, 96, 3);
+        h->out0 = emit_conv3x3(blob, f, 1, id96, &h->tensors.at("output.1.weight"), true);
+    }
+    {   // head 9x9 96 -> 3                                                Generator.py:71
+        Folded f = fold(h, "output.2", "", 1.0, 3, 96, 9);
+        h->head = ConvDev();
+        h->head.w_f32 = blob.put_f32(pack_head_f32(f));
+        h->head.w_bf16 = h->head.w_f32;
+        h->head.bias = blob.put_f32(f.b);
+    }
+
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(s));                 // earlier forwards may still read the old blob
+    if (h->blob_bytes < blob.bytes.size()) {
+        if (h->blob) HIP_TRY(hipFree(h->blob));
+        h->blob = nullptr;
+        h->blob_bytes = 0;
+        HIP_TRY(hipMalloc((void**)&h->blob, blob.bytes.size()));
+        h->blob_bytes = blob.bytes.size();
+    }
+    HIP_TRY(hipMemcpyAsync(h->blob, blob.bytes.data(), blob.bytes.size(), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));                 // host staging buffer dies with this scope
+    h->committed = true;
+    return SRGEN_OK;
+}
+
+int srgen_workspace_bytes(const srgen_handle* h, int n, int dtype, size_t* bytes)
+{
+    if (!h || !bytes) return fail(SRGEN_E_INVALID, "handle or bytes is NULL");
+    if (n < 0) return fail(SRGEN_E_INVALID, "negative batch %d", n);
+    if (dtype != SRGEN_F32 && dtype != SRGEN_BF16) return fail(SRGEN_E_INVALID, "unknown dtype %d", dtype);
+    *bytes = plan_workspace(n > 0 ? n : 1, dtype).total;
+    return SRGEN_OK;
+}
+
+int srgen_forward_taps(srgen_handle* h, const void* x, void* y, void* workspace, size_t workspace_bytes,
+                       int n, int dtype, void* const* taps, void* stream)
+{
+    if (!h) return fail(SRGEN_E_INVALID, "handle is NULL");
+    if (!h->committed) return fail(SRGEN_E_STATE, "srgen_forward before srgen_commit_weights");
+    if (dtype != SRGEN_F32 && dtype != SRGEN_BF16) return fail(SRGEN_E_INVALID, "unknown dtype %d", dtype);
+    if (n < 0) return fail(SRGEN_E_INVALID, "negative batch %d", n);
+    if (n == 0) return SRGEN_OK;                       // empty batch: nothing to do
+    if (!x || !y || !workspace) return fail(SRGEN_E_INVALID, "x, y or workspace is NULL");
+    const Workspace ws = plan_workspace(n, dtype);
+    if (workspace_bytes < ws.total)
+        return fail(SRGEN_E_WORKSPACE, "workspace too small: need %zu bytes for n=%d, got %zu", ws.total, n,
+                    workspace_bytes);
+    if (((uintptr_t)workspace & 255) || ((uintptr_t)x & 15) || ((uintptr_t)y & 3))
+        return fail(SRGEN_E_WORKSPACE, "workspace must be 256-byte aligned, x 16-byte aligned");
+    if (dtype == SRGEN_BF16) return fail(SRGEN_E_UNSUPPORTED, "bf16 forward not built yet");
+
+    hipStream_t s = (hipStream_t)stream;
+    char* W = (char*)workspace;
+    const char* B = h->blob;
+    const bool bf = dtype == SRGEN_BF16;
+    auto F = [&](size_t off) { return (const float*)(B + off); };
+    auto tap = [&](int id, const void* nhwc, int hw) -> hipError_t {
+        if (!taps || !taps[id]) return hipSuccess;
+        return launch_nhwc_to_nchw_f32(nhwc, bf ? 1 : 0, (float*)taps[id], n, hw, kC, s);
+    };
+    auto conv = [&](const ConvDev& d, const void* in, void* out, const void* res, float* pool, int H,
+                    int shuffle) -> hipError_t {
+        Conv3x3Args a;
+        a.in = in; a.out = out;
+        a.wpack = B + (bf ? d.w_bf16 : d.w_f32);
+        a.bias = F(d.bias);
+        a.slope = d.has_slope ? F(d.slope) : nullptr;
+        a.res = res; a.pool_partial = pool;
+        a.N = n; a.H = H; a.W = H;
+        a.cout_blocks = d.cout_blocks; a.shuffle = shuffle;
+        return launch_conv3x3_f32(a, s);
+    };
+
+    void* x1 = W + ws.x1;
+    void* bufs[2] = {W + ws.a, W + ws.b};
+    void* t = W + ws.t;
+    float* pool = (float*)(W + ws.pool);
+
+    {   // x1 = input(x)                                                   Generator.py:75
+        StemArgs a{x, x1, B + h->stem.w_f32, F(h->stem.bias), F(h->stem.slope), n};
+        HIP_TRY(launch_stem_f32(a, s));
+        HIP_TRY(tap(0, x1, kLR * kLR));
+    }
+    const void* cur = x1;                               // x2 = blocks(x1)  Generator.py:76
+    int flip = 0;
+    for (int i = 0; i < h->cfg.num_blocks; ++i) {
+        const bool has_ca = (i == 7 || i == 15);
+        void* nxt = bufs[flip];
+        flip ^= 1;
+        HIP_TRY(conv(h->conv1[i], cur, t, nullptr, nullptr, kLR, 0));
+        HIP_TRY(conv(h->conv2[i], t, nxt, cur, has_ca ? pool : nullptr, kLR, 0));
+        cur = nxt;
+        const int idx = seq_index(i);
+        if (idx == 0) HIP_TRY(tap(1, cur, kLR * kLR));
+        if (idx == 7) HIP_TRY(tap(2, cur, kLR * kLR));
+        if (idx == 16) HIP_TRY(tap(4, cur, kLR * kLR));
+        if (has_ca) {
+            const int k = i == 7 ? 0 : 1;
+            float* sc = (float*)(W + ws.scale[k]);
+            ChanAttnArgs a{nxt, pool, 16, F(h->ca[k].w1), F(h->ca[k].b1), F(h->ca[k].w2), F(h->ca[k].b2),
+                           sc, n, kLR * kLR};
+            HIP_TRY(launch_chan_attn_f32(a, s));
+            HIP_TRY(tap(k == 0 ? 3 : 5, cur, kLR * kLR));
+            if (taps && taps[9 + k])
+                HIP_TRY(hipMemcpyAsync(taps[9 + k], sc, (size_t)n * kC * 4, hipMemcpyDeviceToDevice, s));
+        }
+    }
+    void* m = bufs[flip];                               // x1 + mid(x2)     Generator.py:77-78
+    HIP_TRY(conv(h->mid, cur, m, x1, nullptr, kLR, 0));
+    HIP_TRY(tap(6, m, kLR * kLR));
+    void* u = W + ws.u;                                 // upsample         Generator.py:78, 4-12
+    HIP_TRY(conv(h->up, m, u, nullptr, nullptr, kLR, 1));
+    HIP_TRY(tap(7, u, kHR * kHR));
+    void* v = W + ws.v;                                 // output[0..1]     Generator.py:69-70
+    HIP_TRY(conv(h->out0, u, v, nullptr, nullptr, kHR, 0));
+    HIP_TRY(tap(8, v, kHR * kHR));
+    {   // output[2] + crop                                               Generator.py:71, 80
+        HeadArgs a{v, y, B + h->head.w_f32, F(h->head.bias), n};
+        HIP_TRY(launch_head_f32(a, s));
+    }
+    return SRGEN_OK;
+}
+
+int srgen_forward(srgen_handle* h, const void* x, void* y, void* workspace, size_t workspace_bytes, int n,
+                  int dtype, void* stream)
+{
+    return srgen_forward_taps(h, x, y, workspace, workspace_bytes, n, dtype, nullptr, stream);
+}
+
+int srgen_bilinear_resize(const float* x, float* y, int planes, int hgt, int wid, int oh, int ow, void* stream)
+{
+    if (planes < 0 || hgt <= 0 || wid <= 0 || oh <= 0 || ow <= 0)
+        return fail(SRGEN_E_INVALID, "bad resize shape (%d,%d,%d)->(%d,%d)", planes, hgt, wid, oh, ow);
+    if (planes == 0) return SRGEN_OK;
+    if (!x || !y) return fail(SRGEN_E_INVALID, "x or y is NULL");
+    HIP_TRY(launch_bilinear(x, y, planes, hgt, wid, oh, ow, (hipStream_t)stream));
+    return SRGEN_OK;
+}
+
+int srgen_metrics_scratch_bytes(int n, int c, int hgt, int wid, size_t* bytes)
+{
+    if (!bytes || n <= 0 || c <= 0 || hgt <= 0 || wid <= 0) return fail(SRGEN_E_INVALID, "bad metrics shape");
+    *bytes = align256(metrics_scratch_bytes(n, c, hgt, wid));
+    return SRGEN_OK;
+}
+
+int srgen_metrics(const float* sr, const float* hr, int n, int c, int hgt, int wid, float* out3,
+                  void* scratch, size_t scratch_bytes, void* stream)
+{
+    if (!sr || !hr || !out3 || !scratch) return fail(SRGEN_E_INVALID, "NULL argument");
+    if (n <= 0 || c <= 0 || hgt <= 0 || wid <= 0) return fail(SRGEN_E_INVALID, "bad metrics shape");
+    if (scratch_bytes < metrics_scratch_bytes(n, c, hgt, wid))
+        return fail(SRGEN_E_WORKSPACE, "metrics scratch too small");
+    HIP_TRY(launch_metrics(sr, hr, n, c, hgt, wid, out3, scratch, (hipStream_t)stream));
+    return SRGEN_OK;
+}
+
+}  // extern "C"

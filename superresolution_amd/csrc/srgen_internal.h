@@ -1,0 +1,94 @@
+// srgen_internal.h -- kernel launch interface between srgen_api.cpp (host: fold, pack, plan)
+// and the gfx950 kernel translation units.  Not part of the public ABI (include/srgen.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace srgen {
+
+constexpr int kC = 96;          // trunk width (base_ch)
+constexpr int kLR = 64;         // low-res side
+constexpr int kHR = 128;        // after PixelShuffle(2)
+constexpr int kOut = 125;       // cropped output side (Generator.py:80)
+
+// Internal activation layout: NHWC, C = 96, element = float (F32) or bf16 (BF16).
+
+// ---- 3x3 conv, 96 -> 96*cout_blocks, fused epilogue ------------------------------------
+struct Conv3x3Args {
+    const void* in;        // (N,H,W,96)
+    void* out;             // (N,H,W,96)  or (N,2H,2W,96) when shuffle
+    const void* wpack;     // packed weights, per dtype (see pack_conv3x3_*)
+    const float* bias;     // [96*cout_blocks] folded bias (fp32)
+    const float* slope;    // [96*cout_blocks] PReLU slope per output channel, or nullptr
+    const void* res;       // residual (N,H,W,96) added after activation, or nullptr
+    float* pool_partial;   // [N][tiles_per_image][96] per-tile channel sums, or nullptr
+    int N, H, W;
+    int cout_blocks;       // 1, or 4 for the upsample conv
+    int shuffle;           // 1: PixelShuffle(2) store (cout block b -> sub-pixel (b>>1, b&1))
+};
+
+// ---- 9x9 stem, NCHW 3ch in -> NHWC 96 out, bias + PReLU ---------------------------------
+struct StemArgs {
+    const void* x;         // (N,3,64,64) NCHW, dtype of the forward
+    void* out;             // (N,64,64,96) NHWC
+    const void* wpack;
+    const float* bias;     // [96]
+    const float* slope;    // [96]
+    int N;
+};
+
+// ---- channel attention: pool finish + FC + sigmoid + in-place scale ---------------------
+struct ChanAttnArgs {
+    void* x;               // (N,64,64,96) NHWC, scaled in place
+    const float* pool_partial;   // [N][tiles][96]
+    int tiles;             // partial sums per image
+    const float* w1;       // [12][96]
+    const float* b1;       // [12]
+    const float* w2;       // [96][12]
+    const float* b2;       // [96]
+    float* scale_out;      // [N][96]
+    int N;
+    int hw;                // pixels per image (4096)
+};
+
+// ---- 9x9 head, NHWC 96 in (128x128) -> NCHW 3ch out, cropped to 125x125 -----------------
+struct HeadArgs {
+    const void* in;        // (N,128,128,96) NHWC
+    void* y;               // (N,3,125,125) NCHW, dtype of the forward
+    const void* wpack;
+    const float* bias;     // [3]
+    int N;
+};
+
+// fp32 kernels (srgen_kernels_f32.hip)
+hipError_t launch_stem_f32(const StemArgs& a, hipStream_t s);
+hipError_t launch_conv3x3_f32(const Conv3x3Args& a, hipStream_t s);
+hipError_t launch_chan_attn_f32(const ChanAttnArgs& a, hipStream_t s);
+hipError_t launch_head_f32(const HeadArgs& a, hipStream_t s);
+// bf16 kernels (srgen_kernels_bf16.hip)
+hipError_t launch_stem_bf16(const StemArgs& a, hipStream_t s);
+hipError_t launch_conv3x3_bf16(const Conv3x3Args& a, hipStream_t s);
+hipError_t launch_chan_attn_bf16(const ChanAttnArgs& a, hipStream_t s);
+hipError_t launch_head_bf16(const HeadArgs& a, hipStream_t s);
+
+// misc (srgen_kernels_misc.hip)
+hipError_t launch_nhwc_to_nchw_f32(const void* in, int in_is_bf16, float* out, int N, int HW,
+                                   int C, hipStream_t s);
+hipError_t launch_bilinear(const float* x, float* y, int planes, int h, int w, int oh, int ow,
+                           hipStream_t s);
+size_t metrics_scratch_bytes(int n, int c, int h, int w);
+hipError_t launch_metrics(const float* sr, const float* hr, int n, int c, int h, int w,
+                          float* out3, void* scratch, hipStream_t s);
+
+// ---- packed-weight geometry shared by the packers (host) and the kernels ---------------
+// fp32 3x3: float4 units  [cout_block][tap 9][ci4 24][co 96] -> 4 consecutive ci
+constexpr size_t kConv3x3F32Floats = (size_t)9 * 96 * 96;             // per cout block
+// fp32 stem: [k 256][co 96], k = ky*28 + (kx*3+ci), rows >= 252 and kx*3+ci == 27 are zero
+constexpr int kStemK = 256;
+constexpr size_t kStemF32Floats = (size_t)kStemK * 96;
+// fp32 head: float2 units [ky 9][c8 12][u 2][h 2][n 32] -> ci = 8*c8 + 2*(2u+h) + e,
+//            n = kx*3 + co (27 used, rest zero)
+constexpr size_t kHeadF32Floats = (size_t)9 * 12 * 2 * 2 * 32 * 2;
+
+}  // namespace srgen

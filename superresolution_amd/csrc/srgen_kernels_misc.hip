@@ -1,0 +1,207 @@
+// srgen_kernels_misc.hip -- HBM-bound helpers: layout export for parity taps, the optional
+// bilinear resize, and the validate() metrics (PSNR / SSIM / L1).
+#include "srgen_internal.h"
+
+namespace srgen {
+
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b)
+{
+    return __uint_as_float(((unsigned)b) << 16);
+}
+
+// ---- NHWC (fp32 or bf16) -> NCHW fp32, via a 32x32 LDS transpose -----------------------------
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const void* in, int in_is_bf16,
+                                                           float* out, int HW, int C)
+{
+    __shared__ float t[32][33];
+    const int n = blockIdx.z, p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int pix = p0 + r, c = c0 + tx;
+        float v = 0.f;
+        if (pix < HW && c < C) {
+            const size_t idx = ((size_t)n * HW + pix) * C + c;
+            v = in_is_bf16 ? bf16_bits_to_f32(((const unsigned short*)in)[idx]) : ((const float*)in)[idx];
+        }
+        t[r][tx] = v;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, pix = p0 + tx;
+        if (pix < HW && c < C) out[((size_t)n * C + c) * HW + pix] = t[tx][r];
+    }
+}
+
+hipError_t launch_nhwc_to_nchw_f32(const void* in, int in_is_bf16, float* out, int N, int HW, int C,
+                                   hipStream_t s)
+{
+    dim3 grid((unsigned)((HW + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)N);
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid, dim3(256), 0, s, in, in_is_bf16, out, HW, C);
+    return hipGetLastError();
+}
+
+// ---- bilinear resize, align_corners=False (ATen upsample_bilinear2d semantics) --------------
+// src = max(0, (dst + 0.5) * in/out - 0.5); i0 = floor(src); i1 = i0 + (i0 < in-1); l = src - i0.
+// One thread per output pixel, consecutive lanes -> consecutive ox: coalesced stores, and the
+// 2x2 gathers of neighbouring lanes fall in the same 128-byte lines.
+__global__ __launch_bounds__(256) void bilinear_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                       int planes, int h, int w, int oh, int ow,
+                                                       float sh, float sw)
+{
+    const size_t total = (size_t)planes * oh * ow;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int ox = (int)(i % ow);
+        const size_t t = i / ow;
+        const int oy = (int)(t % oh);
+        const size_t pl = t / oh;
+        float fy = ((float)oy + 0.5f) * sh - 0.5f; fy = fy < 0.f ? 0.f : fy;
+        float fx = ((float)ox + 0.5f) * sw - 0.5f; fx = fx < 0.f ? 0.f : fx;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+        const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+        const float* xs = x + pl * h * w;
+        y[i] = hy * (hx * xs[(size_t)y0 * w + x0] + lx * xs[(size_t)y0 * w + x1]) +
+               ly * (hx * xs[(size_t)y1 * w + x0] + lx * xs[(size_t)y1 * w + x1]);
+    }
+}
+
+hipError_t launch_bilinear(const float* x, float* y, int planes, int h, int w, int oh, int ow, hipStream_t s)
+{
+    const size_t total = (size_t)planes * oh * ow;
+    unsigned grid = (unsigned)((total + 255) / 256);
+    if (grid > 256u * 16u) grid = 256u * 16u;
+    if (grid == 0) return hipSuccess;
+    hipLaunchKernelGGL(bilinear_kernel, dim3(grid), dim3(256), 0, s, x, y, planes, h, w, oh, ow,
+                       (float)h / (float)oh, (float)w / (float)ow);
+    return hipGetLastError();
+}
+
+// ---- PSNR / SSIM / L1 over a batch (utils.py:5-41, train.py:61-68) ---------------------------
+// One workgroup per 32x32 output tile of one (n,c) plane: the 42x42 halo tiles of sr and hr go
+// to LDS once (zero padded, like F.conv2d(padding=5)), a horizontal 11-tap pass builds the five
+// filtered rows in LDS, a vertical pass finishes them; per-workgroup partial sums go to
+// `scratch`, and a single-workgroup second kernel adds them in fixed order in fp64.
+constexpr int MT = 32, MH = MT + 10;
+
+__global__ __launch_bounds__(256) void metrics_tile_kernel(const float* __restrict__ sr,
+                                                           const float* __restrict__ hr, int h, int w,
+                                                           int tiles_x, int tiles_y, float* scratch)
+{
+    __shared__ float a[MH][MH + 1], b[MH][MH + 1];
+    __shared__ float hq[5][MH][MT + 1];
+    __shared__ float red[3][4];
+    float g[11];
+    {   // utils.py:12-16: fp32 gaussian, sigma 1.5, normalised
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 11; ++i) { const float d = (float)(i - 5); g[i] = expf(-(d * d) / (2.f * 1.5f * 1.5f)); s += g[i]; }
+#pragma unroll
+        for (int i = 0; i < 11; ++i) g[i] /= s;
+    }
+    int bid = blockIdx.x;
+    const int tx = bid % tiles_x; bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const size_t plane = bid / tiles_y;
+    const float* ps = sr + plane * h * w;
+    const float* ph = hr + plane * h * w;
+    const int x0 = tx * MT - 5, y0 = ty * MT - 5;
+    for (int i = threadIdx.x; i < MH * MH; i += 256) {
+        const int r = i / MH, c = i - r * MH;
+        const int gy = y0 + r, gx = x0 + c;
+        const bool ok = (unsigned)gy < (unsigned)h && (unsigned)gx < (unsigned)w;
+        a[r][c] = ok ? ps[(size_t)gy * w + gx] : 0.f;
+        b[r][c] = ok ? ph[(size_t)gy * w + gx] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < MH * MT; i += 256) {
+        const int r = i / MT, c = i - r * MT;
+        float mx = 0, my = 0, xx = 0, yy = 0, xy = 0;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            const float va = a[r][c + k], vb = b[r][c + k], gk = g[k];
+            mx += gk * va; my += gk * vb; xx += gk * va * va; yy += gk * vb * vb; xy += gk * va * vb;
+        }
+        hq[0][r][c] = mx; hq[1][r][c] = my; hq[2][r][c] = xx; hq[3][r][c] = yy; hq[4][r][c] = xy;
+    }
+    __syncthreads();
+    float se = 0.f, ae = 0.f, ss = 0.f;
+    for (int i = threadIdx.x; i < MT * MT; i += 256) {
+        const int r = i / MT, c = i - r * MT;
+        const int gy = ty * MT + r, gx = tx * MT + c;
+        if (gy < h && gx < w) {
+            float mx = 0, my = 0, xx = 0, yy = 0, xy = 0;
+#pragma unroll
+            for (int k = 0; k < 11; ++k) {
+                const float gk = g[k];
+                mx += gk * hq[0][r + k][c]; my += gk * hq[1][r + k][c]; xx += gk * hq[2][r + k][c];
+                yy += gk * hq[3][r + k][c]; xy += gk * hq[4][r + k][c];
+            }
+            const float c1 = 0.01f * 0.01f, c2 = 0.03f * 0.03f;
+            const float sxx = xx - mx * mx, syy = yy - my * my, sxy = xy - mx * my;
+            const float num = (2.f * mx * my + c1) * (2.f * sxy + c2);
+            float den = (mx * mx + my * my + c1) * (sxx + syy + c2);
+            den = den < 1e-8f ? 1e-8f : den;
+            ss += num / den;
+            const float d = a[r + 5][c + 5] - b[r + 5][c + 5];
+            se += d * d; ae += fabsf(d);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        se += __shfl_xor(se, off); ae += __shfl_xor(ae, off); ss += __shfl_xor(ss, off);
+    }
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][wv] = se; red[1][wv] = ae; red[2][wv] = ss; }
+    __syncthreads();
+    if (threadIdx.x < 3)
+        scratch[(size_t)blockIdx.x * 3 + threadIdx.x] =
+            (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
+__global__ __launch_bounds__(256) void metrics_final_kernel(const float* scratch, int nblocks,
+                                                            double total, float* out3)
+{
+    __shared__ double red[3][256];
+    double s[3] = {0, 0, 0};
+    for (int i = threadIdx.x; i < nblocks; i += 256)
+        for (int k = 0; k < 3; ++k) s[k] += (double)scratch[(size_t)i * 3 + k];
+    for (int k = 0; k < 3; ++k) red[k][threadIdx.x] = s[k];
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st)
+            for (int k = 0; k < 3; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double mse = red[0][0] / total;
+        out3[0] = (mse == 0.0) ? 100.f : (float)(10.0 * log10(1.0 / mse));   // utils.py:7-9
+        out3[1] = (float)(red[2][0] / total);
+        out3[2] = (float)(red[1][0] / total);
+    }
+}
+
+static inline int metric_blocks(int n, int c, int h, int w)
+{
+    return n * c * ((h + MT - 1) / MT) * ((w + MT - 1) / MT);
+}
+
+size_t metrics_scratch_bytes(int n, int c, int h, int w)
+{
+    return (size_t)metric_blocks(n, c, h, w) * 3 * sizeof(float);
+}
+
+hipError_t launch_metrics(const float* sr, const float* hr, int n, int c, int h, int w, float* out3,
+                          void* scratch, hipStream_t s)
+{
+    const int tiles_x = (w + MT - 1) / MT, tiles_y = (h + MT - 1) / MT;
+    const int nb = metric_blocks(n, c, h, w);
+    hipLaunchKernelGGL(metrics_tile_kernel, dim3((unsigned)nb), dim3(256), 0, s, sr, hr, h, w, tiles_x,
+                       tiles_y, (float*)scratch);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(metrics_final_kernel, dim3(1), dim3(256), 0, s, (const float*)scratch, nb,
+                       (double)n * c * h * w, out3);
+    return hipGetLastError();
+}
+
+}  // namespace srgen

@@ -1,0 +1,60 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) vs the golden fixtures made from the
+real reference, and vs the on-box CPU oracle.  Tolerances are BASELINE.json's: fp32 <= 1e-4
+max error normalised by max|ref|; bf16 within 0.05 dB PSNR of the reference output."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import max_rel
+
+pytestmark = pytest.mark.gpu
+
+FP32_TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def gen():
+    from superresolution_amd import Generator, weights as W
+    g = Generator()
+    g.load_state_dict(W.synthetic_state_dict(0), strict=True)
+    return g.to("cuda").eval()
+
+
+def test_fp32_output_vs_reference_golden(gen, golden, golden_inputs):
+    x = torch.from_numpy(golden_inputs).cuda()
+    y = gen(x)
+    assert y.shape == (2, 3, 125, 125) and y.dtype == torch.float32 and y.is_contiguous()
+    err = max_rel(y.cpu().numpy(), golden["y_dense_sparse"])
+    print("fp32 max rel err vs reference:", err)
+    assert err <= FP32_TOL
+
+
+def test_fp32_layer_taps_vs_reference_golden(gen, golden, golden_inputs):
+    x = torch.from_numpy(golden_inputs[:1]).cuda()
+    y, taps = gen.forward_taps(x)
+    for nm in ("stem", "block0", "block7", "ca8", "block16", "ca17", "skip", "upsample", "output1"):
+        t = taps[nm].cpu().numpy()
+        assert list(t.shape) == list(golden[f"tap_{nm}_shape"]), nm
+        sample = t.reshape(-1)[::64]
+        err = max_rel(sample, golden[f"tap_{nm}_sample"])
+        s, ss = t.astype(np.float64).sum(), (t.astype(np.float64) ** 2).sum()
+        print(nm, err, s, float(golden[f"tap_{nm}_sum"]))
+        assert err <= FP32_TOL, nm
+        assert abs(ss - float(golden[f"tap_{nm}_sumsq"])) <= 1e-4 * float(golden[f"tap_{nm}_sumsq"]), nm
+        assert abs(s - float(golden[f"tap_{nm}_sum"])) <= 1e-4 * np.sqrt(t.size * ss), nm
+    for nm in ("ca8_scale", "ca17_scale"):
+        assert np.abs(taps[nm].cpu().numpy() - golden[nm]).max() <= 1e-5, nm
+
+
+def test_fp32_vs_cpu_oracle_other_seed(synth_sd_np):
+    """Different weights/input seed than the fixtures, checked against the C oracle on the box."""
+    from oracle import oracle as O
+    from superresolution_amd import Generator, weights as W
+    sd = W.synthetic_state_dict(7)
+    g = Generator()
+    g.load_state_dict(sd)
+    g = g.cuda().eval()
+    x = W.synthetic_lr_batch(1, seed=5, kind="sparse")
+    ref = O.generator_forward(W.synthetic_state_dict_numpy(7), x)
+    y = g(torch.from_numpy(x).cuda()).cpu().numpy()
+    assert max_rel(y, ref) <= FP32_TOL
