@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""bench.py -- generator images/s (64x64 -> 125x125) on N MI355X, one process per GPU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype f32|bf16] [--batch B]
+
+A "step" is one eval forward of the drop-in ``Generator`` over one batch of synthetic LR images
+already resident in HBM.  At N=1 the workload is BASELINE.json configs[1]: fp32 eval inference
+(BN folded), batch 256 on one MI355X.  For N>1 (launched by torch.distributed.run) every rank
+runs the same per-GPU batch on its own images (weak scaling, images are independent: no
+data-path collective); the only collective is the metric all-reduce of evaluate(), outside the
+timed forward.  Rank 0 prints ONE JSON line.
+
+Extra objects on that line:
+  roofline      dominant kernel = conv3x3_f32_kernel<64,false> (the 33 trunk 3x3 convs, 75 % of the
+                FLOPs).  achieved = algorithmic FLOPs per launch (2*4096*96*864 per image x batch)
+                / average launch duration measured live with HIP events on the launch stream
+                (srgen_forward_profile); peak = 157.3 TFLOP/s fp32 matrix (MI355X_MICROARCH.md).
+  cpu_baseline  the reference's forward restated with stock torch CPU ops (oracle/torch_ref.py,
+                kind "port": same ATen conv kernels the reference dispatches) on the box's host
+                cores, batch 16, bounded to ~10-20 s.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_IMAGE = 2 * 14_407_045_632
+TRUNK_CONV_FLOP_PER_IMAGE = 2 * 4096 * 96 * 864  # one 96->96 3x3 conv at 64x64
+PEAK = {"f32": 157.3, "bf16": 2500.0}          # dense TFLOP/s, MI355X_MICROARCH.md
+
+
+def cpu_baseline(batch=16, iters=64, threads=None):
+    import numpy as np
+    import torch
+    from oracle import torch_ref
+    from superresolution_amd import weights as W
+    threads = threads or min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    sd = W.synthetic_state_dict(0)
+    x = torch.from_numpy(W.synthetic_lr_batch(batch, seed=0))
+    torch_ref.generator_forward(sd, x[:2])            # warm-up
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        torch_ref.generator_forward(sd, x)
+    dt = time.perf_counter() - t0
+    return {"value": round(batch * iters / dt, 3), "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"{iters} fp32 eval forwards of batch {batch} (64x64->125x125) through oracle/torch_ref.py "
+                      f"(stock torch CPU conv path), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32")
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from superresolution_amd import Generator, weights as W
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    g = Generator()
+    g.load_state_dict(W.synthetic_state_dict(0))
+    g = g.to(dev).eval()
+    # per-rank synthetic LR batch (different images per rank), resident in HBM before timing
+    gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    x = torch.rand((args.batch, 3, 64, 64), generator=gen).to(dev)
+    if args.dtype == "bf16":
+        x = x.to(torch.bfloat16)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        y = g(x)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        y = g(x)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.isfinite(y.float()).all()
+
+    # ---- roofline leg: live HIP-event timing of the dominant kernel ----------------------
+    roof = None
+    kernels = {}
+    if rank == 0:
+        acc = {}
+        reps = 3
+        for _ in range(reps):
+            for k, (ms, cnt) in g.profile_forward(x).items():
+                a = acc.setdefault(k, [0.0, 0])
+                a[0] += ms
+                a[1] += cnt
+        kernels = {k: {"ms_per_launch": round(v[0] / max(v[1], 1), 4), "launches_per_forward": v[1] // reps}
+                   for k, v in acc.items()}
+        ms_launch = acc["conv3x3_trunk"][0] / acc["conv3x3_trunk"][1]
+        achieved = TRUNK_CONV_FLOP_PER_IMAGE * args.batch / (ms_launch * 1e-3) / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", f"traffic_{args.dtype}.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("conv3x3_trunk_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roof = {"bound": "mfma", "kernel": f"conv3x3_{args.dtype}_kernel<64,false>",
+                "achieved": round(achieved, 2), "peak": PEAK[args.dtype], "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK[args.dtype], 4), "traffic": traffic,
+                "ms_per_launch": round(ms_launch, 4),
+                "flop_per_launch": TRUNK_CONV_FLOP_PER_IMAGE * args.batch}
+
+    if rank == 0:
+        imgs = args.batch * world * args.steps
+        value = imgs / dt
+        out = {
+            "metric": "generator images/s (64x64->125x125)", "value": round(value, 2), "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: Generator eval inference (BN folded), "
+                                   f"batch {args.batch} of 3x64x64 per GPU -> 3x125x125, {args.dtype}",
+                       "batch_per_gpu": args.batch, "global_batch": args.batch * world,
+                       "parallelism": f"batch-sharded x{world}, weights replicated"},
+            "end_to_end_tflops": round(value * FLOP_PER_IMAGE / 1e12, 2),
+            "end_to_end_frac_of_peak": round(value / world * FLOP_PER_IMAGE / 1e12 / PEAK[args.dtype], 4),
+            "roofline": roof, "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

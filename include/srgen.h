@@ -105,6 +105,23 @@ SRGEN_API int srgen_forward_taps(srgen_handle* h, const void* x, void* y, void* 
                        size_t workspace_bytes, int n, int dtype, void* const* taps,
                        void* stream);
 
+/* Measurement aid for bench.py's roofline leg; no counterpart in the reference.  Runs one
+ * forward with a HIP event pair around every kernel launch on `stream`, synchronises the
+ * stream, and returns per kernel class the summed device time (ms) and the launch count.
+ * Creates/destroys events: not for the serving path. */
+enum {
+    SRGEN_K_STEM = 0,           /* stem_*_kernel                          1 launch            */
+    SRGEN_K_CONV3X3_TRUNK = 1,  /* conv3x3_*_kernel<64,false>             2*num_blocks + 1    */
+    SRGEN_K_CONV3X3_UP = 2,     /* conv3x3_*_kernel<64,true>  (96->384)   1                   */
+    SRGEN_K_CONV3X3_HR = 3,     /* conv3x3_*_kernel<128,false>            1                   */
+    SRGEN_K_CHAN_ATTN = 4,      /* chan_attn_*_kernel                     up to 2             */
+    SRGEN_K_HEAD = 5,           /* head_*_kernel                          1                   */
+    SRGEN_NUM_KCLASS = 6
+};
+SRGEN_API int srgen_forward_profile(srgen_handle* h, const void* x, void* y, void* workspace,
+                          size_t workspace_bytes, int n, int dtype, void* stream,
+                          float* ms_per_class, int* launches_per_class);
+
 /* Optional op named by BASELINE.json's north_star, NOT on the reference's forward path
  * (Generator.py:80 crops; only README.md:52 mentions bilinear): coalesced bilinear resize
  * with torch.nn.functional.interpolate(mode='bilinear', align_corners=False) semantics.

@@ -15,6 +15,8 @@ NUM_TAPS = 11
 TAP_NAMES = ("stem", "block0", "block7", "ca8", "block16", "ca17", "skip", "upsample", "output1",
              "ca8_scale", "ca17_scale")
 
+KCLASS_NAMES = ("stem", "conv3x3_trunk", "conv3x3_up", "conv3x3_hr", "chan_attn", "head")
+
 _lib = None
 
 
@@ -55,11 +57,13 @@ def lib() -> ctypes.CDLL:
     L.srgen_workspace_bytes.argtypes = [vp, i, i, ctypes.POINTER(sz)]
     L.srgen_forward.argtypes = [vp, vp, vp, vp, sz, i, i, vp]
     L.srgen_forward_taps.argtypes = [vp, vp, vp, vp, sz, i, i, ctypes.POINTER(vp), vp]
+    L.srgen_forward_profile.argtypes = [vp, vp, vp, vp, sz, i, i, vp, ctypes.POINTER(ctypes.c_float),
+                                        ctypes.POINTER(ctypes.c_int)]
     L.srgen_bilinear_resize.argtypes = [vp, vp, i, i, i, i, i, vp]
     L.srgen_metrics_scratch_bytes.argtypes = [i, i, i, i, ctypes.POINTER(sz)]
     L.srgen_metrics.argtypes = [vp, vp, i, i, i, i, vp, vp, sz, vp]
     for name in ("srgen_create", "srgen_destroy", "srgen_set_tensor", "srgen_commit_weights",
-                 "srgen_workspace_bytes", "srgen_forward", "srgen_forward_taps", "srgen_bilinear_resize",
+                 "srgen_workspace_bytes", "srgen_forward", "srgen_forward_taps", "srgen_forward_profile", "srgen_bilinear_resize",
                  "srgen_metrics_scratch_bytes", "srgen_metrics"):
         getattr(L, name).restype = i
     if L.srgen_abi_version() != 1:

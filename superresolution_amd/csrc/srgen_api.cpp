@@ -261,6 +261,13 @@ ConvDev emit_conv3x3(Blob& blob, const Folded& f, int cb, const std::vector<int>
     return d;
 }
 
+// Per-kernel-class device timing for bench.py's roofline leg (srgen_forward_profile).
+struct Prof {
+    hipEvent_t ev[2 * 64];
+    int cls[64];
+    int count = 0;
+};
+
 struct Workspace {
     size_t x1, a, b, t, u, v, pool, scale[2], total;
 };
@@ -434,8 +441,8 @@ int srgen_workspace_bytes(const srgen_handle* h, int n, int dtype, size_t* bytes
     return SRGEN_OK;
 }
 
-int srgen_forward_taps(srgen_handle* h, const void* x, void* y, void* workspace, size_t workspace_bytes,
-                       int n, int dtype, void* const* taps, void* stream)
+static int run_forward(srgen_handle* h, const void* x, void* y, void* workspace, size_t workspace_bytes,
+                       int n, int dtype, void* const* taps, void* stream, Prof* prof)
 {
     if (!h) return fail(SRGEN_E_INVALID, "handle is NULL");
     if (!h->committed) return fail(SRGEN_E_STATE, "srgen_forward before srgen_commit_weights");
@@ -460,6 +467,16 @@ int srgen_forward_taps(srgen_handle* h, const void* x, void* y, void* workspace,
         if (!taps || !taps[id]) return hipSuccess;
         return launch_nhwc_to_nchw_f32(nhwc, bf ? 1 : 0, (float*)taps[id], n, hw, kC, s);
     };
+    auto tick = [&](int cls) -> hipError_t {            // event before a launch (profiling only)
+        if (!prof) return hipSuccess;
+        if (prof->count >= 64) return hipErrorInvalidValue;
+        prof->cls[prof->count] = cls;
+        return hipEventRecord(prof->ev[2 * prof->count], s);
+    };
+    auto tock = [&]() -> hipError_t {                   // event after it
+        if (!prof) return hipSuccess;
+        return hipEventRecord(prof->ev[2 * prof->count++ + 1], s);
+    };
     auto conv = [&](const ConvDev& d, const void* in, void* out, const void* res, float* pool, int H,
                     int shuffle) -> hipError_t {
         Conv3x3Args a;
@@ -470,7 +487,11 @@ int srgen_forward_taps(srgen_handle* h, const void* x, void* y, void* workspace,
         a.res = res; a.pool_partial = pool;
         a.N = n; a.H = H; a.W = H;
         a.cout_blocks = d.cout_blocks; a.shuffle = shuffle;
-        return launch_conv3x3_f32(a, s);
+        hipError_t e = tick(shuffle ? SRGEN_K_CONV3X3_UP : (H == kLR ? SRGEN_K_CONV3X3_TRUNK : SRGEN_K_CONV3X3_HR));
+        if (e != hipSuccess) return e;
+        e = launch_conv3x3_f32(a, s);
+        if (e != hipSuccess) return e;
+        return tock();
     };
 
     void* x1 = W + ws.x1;
@@ -480,7 +501,9 @@ int srgen_forward_taps(srgen_handle* h, const void* x, void* y, void* workspace,
 
     {   // x1 = input(x)                                                   Generator.py:75
         StemArgs a{x, x1, B + h->stem.w_f32, F(h->stem.bias), F(h->stem.slope), n};
+        HIP_TRY(tick(SRGEN_K_STEM));
         HIP_TRY(launch_stem_f32(a, s));
+        HIP_TRY(tock());
         HIP_TRY(tap(0, x1, kLR * kLR));
     }
     const void* cur = x1;                               // x2 = blocks(x1)  Generator.py:76
@@ -501,7 +524,9 @@ int srgen_forward_taps(srgen_handle* h, const void* x, void* y, void* workspace,
             float* sc = (float*)(W + ws.scale[k]);
             ChanAttnArgs a{nxt, pool, 16, F(h->ca[k].w1), F(h->ca[k].b1), F(h->ca[k].w2), F(h->ca[k].b2),
                            sc, n, kLR * kLR};
+            HIP_TRY(tick(SRGEN_K_CHAN_ATTN));
             HIP_TRY(launch_chan_attn_f32(a, s));
+            HIP_TRY(tock());
             HIP_TRY(tap(k == 0 ? 3 : 5, cur, kLR * kLR));
             if (taps && taps[9 + k])
                 HIP_TRY(hipMemcpyAsync(taps[9 + k], sc, (size_t)n * kC * 4, hipMemcpyDeviceToDevice, s));
@@ -518,9 +543,42 @@ int srgen_forward_taps(srgen_handle* h, const void* x, void* y, void* workspace,
     HIP_TRY(tap(8, v, kHR * kHR));
     {   // output[2] + crop                                               Generator.py:71, 80
         HeadArgs a{v, y, B + h->head.w_f32, F(h->head.bias), n};
+        HIP_TRY(tick(SRGEN_K_HEAD));
         HIP_TRY(launch_head_f32(a, s));
+        HIP_TRY(tock());
     }
     return SRGEN_OK;
+}
+
+int srgen_forward_taps(srgen_handle* h, const void* x, void* y, void* workspace, size_t workspace_bytes,
+                       int n, int dtype, void* const* taps, void* stream)
+{
+    return run_forward(h, x, y, workspace, workspace_bytes, n, dtype, taps, stream, nullptr);
+}
+
+int srgen_forward_profile(srgen_handle* h, const void* x, void* y, void* workspace, size_t workspace_bytes,
+                          int n, int dtype, void* stream, float* ms_per_class, int* launches_per_class)
+{
+    if (!ms_per_class || !launches_per_class) return fail(SRGEN_E_INVALID, "NULL output array");
+    if (h && h->cfg.num_blocks > 24) return fail(SRGEN_E_UNSUPPORTED, "profile supports num_blocks <= 24");
+    Prof prof;
+    for (int i = 0; i < 128; ++i) HIP_TRY(hipEventCreate(&prof.ev[i]));
+    int rc = run_forward(h, x, y, workspace, workspace_bytes, n, dtype, nullptr, stream, &prof);
+    if (rc == SRGEN_OK) {
+        hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+        if (e != hipSuccess) rc = fail(SRGEN_E_HIP, "hipStreamSynchronize: %s", hipGetErrorString(e));
+    }
+    for (int k = 0; k < SRGEN_NUM_KCLASS; ++k) { ms_per_class[k] = 0.f; launches_per_class[k] = 0; }
+    if (rc == SRGEN_OK)
+        for (int i = 0; i < prof.count; ++i) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, prof.ev[2 * i], prof.ev[2 * i + 1]) == hipSuccess) {
+                ms_per_class[prof.cls[i]] += ms;
+                launches_per_class[prof.cls[i]] += 1;
+            }
+        }
+    for (int i = 0; i < 128; ++i) (void)hipEventDestroy(prof.ev[i]);
+    return rc;
 }
 
 int srgen_forward(srgen_handle* h, const void* x, void* y, void* workspace, size_t workspace_bytes, int n,

@@ -40,11 +40,15 @@ __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >
 constexpr int T3_H = 4, T3_W = 64, T3_HH = 6, T3_HW = 66, T3_CK = 32, T3_PS = 36;
 constexpr int T3_LDS_BYTES = T3_HH * T3_HW * T3_PS * 4;   // 57,024
 
+// HW: image side (64 trunk / 128 output[0]); SHUFFLE: PixelShuffle(2) store (upsample conv).
+// Distinct instantiations give the trunk, upsample and output[0] launches their own names in
+// rocprofv3 kernel traces.
+template <int HW, bool SHUFFLE>
 __global__ __launch_bounds__(256, 2) void conv3x3_f32_kernel(Conv3x3Args a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, p = lane & 31;
-    const int tiles_x = a.W / T3_W, tiles_y = a.H / T3_H;
+    constexpr int tiles_x = HW / T3_W, tiles_y = HW / T3_H;
     int b = blockIdx.x;
     const int tx = b % tiles_x; b /= tiles_x;
     const int ty = b % tiles_y;
@@ -60,7 +64,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32_kernel(Conv3x3Args a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-    const float* in = (const float*)a.in + (size_t)n * a.H * a.W * kC;
+    const float* in = (const float*)a.in + (size_t)n * HW * HW * kC;
     const f32x4* wp = (const f32x4*)a.wpack + (size_t)cb * 9 * 24 * 96;
 
     for (int ck = 0; ck < 3; ++ck) {
@@ -74,8 +78,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32_kernel(Conv3x3Args a)
                 const int r = pix / T3_HW, c = pix - r * T3_HW;
                 const int gy = y0 - 1 + r, gx = x0 - 1 + c;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if ((unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W)
-                    v = *(const f32x4*)(in + ((size_t)gy * a.W + gx) * kC + ck * T3_CK + q * 4);
+                if ((unsigned)gy < (unsigned)HW && (unsigned)gx < (unsigned)HW)
+                    v = *(const f32x4*)(in + ((size_t)gy * HW + gx) * kC + ck * T3_CK + q * 4);
                 *(f32x4*)(smem + pix * T3_PS + q * 4) = v;
             }
         }
@@ -114,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32_kernel(Conv3x3Args a)
         slope[nt] = a.slope ? a.slope[co] : 1.f;
         pool[nt] = 0.f;
     }
-    const float* res = a.res ? (const float*)a.res + (size_t)n * a.H * a.W * kC : nullptr;
+    const float* res = a.res ? (const float*)a.res + (size_t)n * HW * HW * kC : nullptr;
     float* out = (float*)a.out;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -122,15 +126,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32_kernel(Conv3x3Args a)
         for (int r = 0; r < 16; ++r) {
             const int x = x0 + 32 * mt + acc_row(r, h);
             size_t o;
-            if (a.shuffle)
-                o = (((size_t)n * 2 * a.H + 2 * y + (cb >> 1)) * 2 * a.W + 2 * x + (cb & 1)) * kC;
+            if (SHUFFLE)
+                o = (((size_t)n * 2 * HW + 2 * y + (cb >> 1)) * 2 * HW + 2 * x + (cb & 1)) * kC;
             else
-                o = (((size_t)n * a.H + y) * a.W + x) * kC;
+                o = (((size_t)n * HW + y) * HW + x) * kC;
 #pragma unroll
             for (int nt = 0; nt < 3; ++nt) {
                 float v = acc[mt][nt][r] + bias[nt];
                 v = v >= 0.f ? v : v * slope[nt];
-                if (res) v += res[((size_t)y * a.W + x) * kC + nt * 32 + p];
+                if (res) v += res[((size_t)y * HW + x) * kC + nt * 32 + p];
                 out[o + nt * 32 + p] = v;
                 pool[nt] += v;
             }
@@ -154,9 +158,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32_kernel(Conv3x3Args a)
 
 hipError_t launch_conv3x3_f32(const Conv3x3Args& a, hipStream_t s)
 {
-    if (a.H % T3_H || a.W % T3_W) return hipErrorInvalidValue;
+    if (a.H != a.W) return hipErrorInvalidValue;
     dim3 grid((unsigned)(a.N * (a.H / T3_H) * (a.W / T3_W)), (unsigned)a.cout_blocks);
-    hipLaunchKernelGGL(conv3x3_f32_kernel, grid, dim3(256), T3_LDS_BYTES, s, a);
+    if (a.H == kLR && !a.shuffle)
+        hipLaunchKernelGGL((conv3x3_f32_kernel<kLR, false>), grid, dim3(256), T3_LDS_BYTES, s, a);
+    else if (a.H == kLR && a.shuffle)
+        hipLaunchKernelGGL((conv3x3_f32_kernel<kLR, true>), grid, dim3(256), T3_LDS_BYTES, s, a);
+    else if (a.H == kHR && !a.shuffle)
+        hipLaunchKernelGGL((conv3x3_f32_kernel<kHR, false>), grid, dim3(256), T3_LDS_BYTES, s, a);
+    else
+        return hipErrorInvalidValue;
     return hipGetLastError();
 }
 

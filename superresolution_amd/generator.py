@@ -191,6 +191,22 @@ class Generator(nn.Module):
                 taps.update(dict(zip(_lib.TAP_NAMES, bufs)))
         return y
 
+    def profile_forward(self, x: torch.Tensor):
+        """One forward with a HIP event pair around every launch (srgen_forward_profile).
+        Returns {kernel class: (summed device ms, launches)}.  Synchronises the stream."""
+        xc, code, dt = self._prepare(x)
+        n, idx = xc.shape[0], xc.device.index
+        y = torch.empty((n, self.in_ch, self.OUT, self.OUT), dtype=dt, device=xc.device)
+        h = self._handle(xc.device)
+        ws = self._ws(h, idx, n, code)
+        ms = (ctypes.c_float * len(_lib.KCLASS_NAMES))()
+        cnt = (ctypes.c_int * len(_lib.KCLASS_NAMES))()
+        with torch.cuda.device(idx):
+            stream = torch.cuda.current_stream(idx).cuda_stream
+            _lib.check(_lib.lib().srgen_forward_profile(h, xc.data_ptr(), y.data_ptr(), ws.data_ptr(),
+                                                        ws.numel(), n, code, stream, ms, cnt))
+        return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(_lib.KCLASS_NAMES)}
+
     # ---- module protocol -------------------------------------------------------------------
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)
