@@ -236,6 +236,41 @@ std::vector<float> pack_head_f32(const Folded& f)
     return p;
 }
 
+// bf16 stem: 8-element units [ky 9][s 3][h 2][co 96]; element e -> kx = 4s + 2h + (e>>2),
+// ci = e & 3 (zero where kx >= 9 or ci == 3).
+std::vector<uint16_t> pack_stem_bf16(const Folded& f)
+{
+    std::vector<uint16_t> p((size_t)9 * 3 * 2 * 96 * 8, 0);
+    for (int ky = 0; ky < 9; ++ky)
+        for (int s = 0; s < 3; ++s)
+            for (int hh = 0; hh < 2; ++hh)
+                for (int co = 0; co < 96; ++co)
+                    for (int e = 0; e < 8; ++e) {
+                        const int kx = 4 * s + 2 * hh + (e >> 2), ci = e & 3;
+                        if (kx < 9 && ci < 3)
+                            p[((((size_t)ky * 3 + s) * 2 + hh) * 96 + co) * 8 + e] =
+                                f32_to_bf16(f.w[(((size_t)co * 3 + ci) * 9 + ky) * 9 + kx]);
+                    }
+    return p;
+}
+
+// bf16 head: 8-element units [ky 9][g 6][h 2][n 32]; ci = 16g + 8h + e; n = kx*3 + co.
+std::vector<uint16_t> pack_head_bf16(const Folded& f)
+{
+    std::vector<uint16_t> p((size_t)9 * 6 * 2 * 32 * 8, 0);
+    for (int ky = 0; ky < 9; ++ky)
+        for (int g = 0; g < 6; ++g)
+            for (int hh = 0; hh < 2; ++hh)
+                for (int kx = 0; kx < 9; ++kx)
+                    for (int co = 0; co < 3; ++co)
+                        for (int e = 0; e < 8; ++e) {
+                            const int ci = 16 * g + 8 * hh + e, n = kx * 3 + co;
+                            p[((((size_t)ky * 6 + g) * 2 + hh) * 32 + n) * 8 + e] =
+                                f32_to_bf16(f.w[(((size_t)co * 96 + ci) * 9 + ky) * 9 + kx]);
+                        }
+    return p;
+}
+
 std::vector<int> identity_perm(int n)
 {
     std::vector<int> v(n);
@@ -370,7 +405,7 @@ int srgen_commit_weights(srgen_handle* h, void* stream)
         Folded f = fold(h, "input.0", "", 1.0, 96, 3, 9);
         h->stem = ConvDev();
         h->stem.w_f32 = blob.put_f32(pack_stem_f32(f));
-        h->stem.w_bf16 = h->stem.w_f32;     // the stem runs its 0.66 % of the FLOPs in fp32
+        h->stem.w_bf16 = blob.put_u16(pack_stem_bf16(f));
         h->stem.bias = blob.put_f32(f.b);
         h->stem.slope = blob.put_f32(std::vector<float>(96, h->tensors.at("input.1.weight")[0]));
         h->stem.has_slope = true;
@@ -412,7 +447,7 @@ int srgen_commit_weights(srgen_handle* h, void* stream)
         Folded f = fold(h, "output.2", "", 1.0, 3, 96, 9);
         h->head = ConvDev();
         h->head.w_f32 = blob.put_f32(pack_head_f32(f));
-        h->head.w_bf16 = h->head.w_f32;
+        h->head.w_bf16 = blob.put_u16(pack_head_bf16(f));
         h->head.bias = blob.put_f32(f.b);
     }
 
@@ -456,7 +491,6 @@ static int run_forward(srgen_handle* h, const void* x, void* y, void* workspace,
                     workspace_bytes);
     if (((uintptr_t)workspace & 255) || ((uintptr_t)x & 15) || ((uintptr_t)y & 3))
         return fail(SRGEN_E_WORKSPACE, "workspace must be 256-byte aligned, x 16-byte aligned");
-    if (dtype == SRGEN_BF16) return fail(SRGEN_E_UNSUPPORTED, "bf16 forward not built yet");
 
     hipStream_t s = (hipStream_t)stream;
     char* W = (char*)workspace;
@@ -489,7 +523,7 @@ static int run_forward(srgen_handle* h, const void* x, void* y, void* workspace,
         a.cout_blocks = d.cout_blocks; a.shuffle = shuffle;
         hipError_t e = tick(shuffle ? SRGEN_K_CONV3X3_UP : (H == kLR ? SRGEN_K_CONV3X3_TRUNK : SRGEN_K_CONV3X3_HR));
         if (e != hipSuccess) return e;
-        e = launch_conv3x3_f32(a, s);
+        e = bf ? launch_conv3x3_bf16(a, s) : launch_conv3x3_f32(a, s);
         if (e != hipSuccess) return e;
         return tock();
     };
@@ -500,9 +534,9 @@ static int run_forward(srgen_handle* h, const void* x, void* y, void* workspace,
     float* pool = (float*)(W + ws.pool);
 
     {   // x1 = input(x)                                                   Generator.py:75
-        StemArgs a{x, x1, B + h->stem.w_f32, F(h->stem.bias), F(h->stem.slope), n};
+        StemArgs a{x, x1, B + (bf ? h->stem.w_bf16 : h->stem.w_f32), F(h->stem.bias), F(h->stem.slope), n};
         HIP_TRY(tick(SRGEN_K_STEM));
-        HIP_TRY(launch_stem_f32(a, s));
+        HIP_TRY(bf ? launch_stem_bf16(a, s) : launch_stem_f32(a, s));
         HIP_TRY(tock());
         HIP_TRY(tap(0, x1, kLR * kLR));
     }
@@ -525,7 +559,7 @@ static int run_forward(srgen_handle* h, const void* x, void* y, void* workspace,
             ChanAttnArgs a{nxt, pool, 16, F(h->ca[k].w1), F(h->ca[k].b1), F(h->ca[k].w2), F(h->ca[k].b2),
                            sc, n, kLR * kLR};
             HIP_TRY(tick(SRGEN_K_CHAN_ATTN));
-            HIP_TRY(launch_chan_attn_f32(a, s));
+            HIP_TRY(bf ? launch_chan_attn_bf16(a, s) : launch_chan_attn_f32(a, s));
             HIP_TRY(tock());
             HIP_TRY(tap(k == 0 ? 3 : 5, cur, kLR * kLR));
             if (taps && taps[9 + k])
@@ -542,9 +576,9 @@ static int run_forward(srgen_handle* h, const void* x, void* y, void* workspace,
     HIP_TRY(conv(h->out0, u, v, nullptr, nullptr, kHR, 0));
     HIP_TRY(tap(8, v, kHR * kHR));
     {   // output[2] + crop                                               Generator.py:71, 80
-        HeadArgs a{v, y, B + h->head.w_f32, F(h->head.bias), n};
+        HeadArgs a{v, y, B + (bf ? h->head.w_bf16 : h->head.w_f32), F(h->head.bias), n};
         HIP_TRY(tick(SRGEN_K_HEAD));
-        HIP_TRY(launch_head_f32(a, s));
+        HIP_TRY(bf ? launch_head_bf16(a, s) : launch_head_f32(a, s));
         HIP_TRY(tock());
     }
     return SRGEN_OK;

@@ -58,3 +58,52 @@ def test_fp32_vs_cpu_oracle_other_seed(synth_sd_np):
     ref = O.generator_forward(W.synthetic_state_dict_numpy(7), x)
     y = g(torch.from_numpy(x).cuda()).cpu().numpy()
     assert max_rel(y, ref) <= FP32_TOL
+
+
+# ---- bf16 (BASELINE.json configs[2]) --------------------------------------------------------
+def _psnr(a, b):
+    mse = float(np.mean((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2))
+    return 100.0 if mse == 0 else 10.0 * np.log10(1.0 / mse)
+
+
+def test_bf16_output_within_0p05_db_of_reference(gen, golden, golden_inputs):
+    """north_star: bf16 agrees to within 0.05 dB PSNR of the reference output.  PSNR is taken
+    against a synthetic hr target with utils.psnr semantics (max_val = 1); the direct
+    PSNR(y_bf16, y_ref_fp32) is also checked against the floor the reference's own bf16 autocast
+    reaches on the same inputs (fixture y_bf16_autocast: ~76 dB)."""
+    from superresolution_amd import weights as W
+    x = torch.from_numpy(golden_inputs).cuda().to(torch.bfloat16)
+    y = gen(x)
+    assert y.dtype == torch.bfloat16 and y.shape == (2, 3, 125, 125)
+    yb = y.float().cpu().numpy()
+    ref = golden["y_dense_sparse"]
+    hr = W.synthetic_hr_batch(2, seed=1)
+    d = abs(_psnr(yb, hr) - _psnr(ref, hr))
+    direct = _psnr(yb, ref)
+    floor = _psnr(golden["y_bf16_autocast"], ref)
+    print(f"bf16: |dPSNR vs hr| = {d:.5f} dB, PSNR(y_bf16, y_ref) = {direct:.2f} dB "
+          f"(reference's own bf16 autocast: {floor:.2f} dB), max-abs {np.abs(yb - ref).max():.3e}")
+    assert d <= 0.05
+    assert direct >= floor - 6.0          # within 2x (6 dB) of the reference's own bf16 error
+
+
+def test_bf16_autocast_returns_bf16(gen, golden_inputs):
+    x = torch.from_numpy(golden_inputs[:1]).cuda()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = gen(x)
+    assert y.dtype == torch.bfloat16          # SURVEY.md 8(b): bf16 under autocast [probe]
+    y32 = gen(x)
+    assert y32.dtype == torch.float32
+    assert _psnr(y.float().cpu().numpy(), y32.cpu().numpy()) > 60.0
+
+
+def test_bf16_layer_taps(gen, golden, golden_inputs):
+    x = torch.from_numpy(golden_inputs[:1]).cuda().to(torch.bfloat16)
+    _, taps = gen.forward_taps(x)
+    for nm in ("stem", "block0", "block7", "ca8", "block16", "ca17", "skip", "upsample", "output1"):
+        t = taps[nm].cpu().numpy().reshape(-1)[::64]
+        err = max_rel(t, golden[f"tap_{nm}_sample"])
+        print("bf16 tap", nm, err)
+        assert err <= 3e-2, nm
+    for nm in ("ca8_scale", "ca17_scale"):
+        assert np.abs(taps[nm].cpu().numpy() - golden[nm]).max() <= 5e-3, nm
