@@ -1,0 +1,449 @@
+// srgen_conv3x3_bf16.hip -- gfx950 bf16 3x3 conv 96 -> 96 (x cout_blocks), implicit GEMM on
+// v_mfma_f32_32x32x16_bf16, software-pipelined.
+//
+// Reference sites (file:line into /root/reference): Generator.py:34,37 (ResBlock convs; eval
+// BatchNorm :35,38 and the 0.1 of :42 are folded into w, b on the host), :62 (mid), :7
+// (upsample conv, PixelShuffle :8 folded into the store address), :69 (output[0]); PReLU
+// :36,:9,:70 and the residual adds :42,:78 are the epilogue.
+//
+// Structure (one workgroup = 4 waves = 4 rows x 64 pixels x 96 output channels; two workgroups
+// per CU so one workgroup's prologue / epilogue is covered by the other's MFMAs):
+//   * GEMM view: M = pixels, N = 96 co, K = 9 taps x 96 ci, walked as 2 ci-chunks x 9 taps x
+//     3 k16-steps = 54 steps of 6 MFMAs per wave;
+//   * A (activations): zero-padded 6 x 66 pixel halo tile of one 48-ci chunk in LDS, pixel
+//     stride 112 B (7 x 16 B, odd => conflict-free ds_read_b128); chunk 1 is fetched into
+//     registers under the last tap of chunk 0;
+//   * B (weights): one 9 KB slab per (tap, chunk) copied global -> LDS with global_load_lds
+//     into a 3-deep ring, issued two phases ahead, so the fragments of the next phase's first
+//     step can be read before the barrier that ends the current phase;
+//   * fragments are double-buffered in registers: the ds_reads of step s+1 are issued before
+//     the MFMAs of step s (the compiler alone serialises read -> wait -> MFMA);
+//   * epilogue: bias -> PReLU -> fp32 transpose through LDS -> (+ residual) -> 16-byte
+//     row-contiguous bf16 stores; optional per-tile channel sums for ChannelAttention's pool.
+#include "srgen_internal.h"
+
+#include <type_traits>
+
+namespace srgen {
+namespace c3 {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base)
+{
+    // async 16-byte global -> LDS copy: LDS address = wave-uniform base + lane*16
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ float bf16_lo(unsigned v) { return __uint_as_float(v << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned v) { return __uint_as_float(v & 0xffff0000u); }
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi)
+{
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    bf16x2 t = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(unsigned, t);
+}
+
+constexpr int TH = 4, TW = 64, HH = 6, HWP = 66;
+constexpr int CK = 48;                            // ci per chunk
+constexpr int PS = 112;                           // A pixel stride, bytes (96 + 16 pad)
+constexpr int A_BYTES = HH * HWP * PS;            // 44,352
+constexpr int SLAB = 6 * 96 * 16;                 // 9,216: one (tap, chunk) weight slab
+constexpr int NRING = 3;
+constexpr int BS_OFF = A_BYTES + NRING * SLAB;    // bias[4][96], slope[4][96] (fp32)
+constexpr int LDS_BYTES = BS_OFF + 2 * 4 * 96 * 4;   // 75,072 (two workgroups per CU)
+constexpr int A_ITEMS = HH * HWP * 6;             // 16-byte pieces per chunk (2,376)
+constexpr int MAX_WGS = 512;                      // persistent grid: 2 workgroups x 256 CUs
+
+struct Frags { bf16x8 a0, a1, b0, b1, b2; };
+
+#ifdef SRGEN_C3_STAMPS      // development only (tools/convbench): per-work-item phase timestamps
+__device__ long long* g_stamps = nullptr;
+#define C3_STAMP(k)                                                                       \
+    do {                                                                                  \
+        if (g_stamps && tid == 0) g_stamps[(size_t)item * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define C3_STAMP(k) do { } while (0)
+#endif
+
+__device__ __forceinline__ void load_frags(Frags& f, const char* Ab, const char* Bb, int g)
+{
+    f.a0 = *(const bf16x8*)(Ab + g * 32);
+    f.a1 = *(const bf16x8*)(Ab + 32 * PS + g * 32);
+    f.b0 = *(const bf16x8*)(Bb + (2 * g * 96) * 16);
+    f.b1 = *(const bf16x8*)(Bb + (2 * g * 96 + 32) * 16);
+    f.b2 = *(const bf16x8*)(Bb + (2 * g * 96 + 64) * 16);
+}
+
+// The weights are the MFMA's A operand (rows = output channels) and the pixels its B operand
+// (columns = pixels), so accumulator register q of lane l is
+//     C[co = 32*nt + (q&3) + 8*(q>>2) + 4*(l>>5)][pixel = 32*mt + (l&31)]:
+// 4 consecutive channels of ONE pixel sit in 4 consecutive registers -- bf16 packing, the
+// residual add and the NHWC store need no transpose through LDS.
+__device__ __forceinline__ void mma_step(f32x16 (&acc)[2][3], const Frags& f)
+{
+    acc[0][0] = MFMA_BF16(f.b0, f.a0, acc[0][0]);
+    acc[1][0] = MFMA_BF16(f.b0, f.a1, acc[1][0]);
+    acc[0][1] = MFMA_BF16(f.b1, f.a0, acc[0][1]);
+    acc[1][1] = MFMA_BF16(f.b1, f.a1, acc[1][1]);
+    acc[0][2] = MFMA_BF16(f.b2, f.a0, acc[0][2]);
+    acc[1][2] = MFMA_BF16(f.b2, f.a1, acc[1][2]);
+}
+
+// Returns v, but opaque to the optimiser: index arithmetic derived from it is recomputed where it
+// is used instead of being hoisted out of the persistent loop and kept in (spilled) registers.
+__device__ __forceinline__ int opaque(int v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+// v_permlane32_swap: lanes 32-63 of x trade places with lanes 0-31 of y.
+__device__ __forceinline__ void swap32(unsigned& x, unsigned& y)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(x, y, false, false);
+    x = r[0];
+    y = r[1];
+}
+
+// Work item = (tile of 4 rows x 64 pixels, cout block).  Persistent workgroups: ids b, b+8, ...
+// share an XCD (private L2) under round-robin placement, so XCD x owns the contiguous item
+// range [x*per, (x+1)*per) and its workgroups walk it with stride (workgroups per XCD); the
+// halo rows two neighbouring tiles share then come from that XCD's L2.  Speed only.
+struct Item { int n, ty, tx, cb; };
+
+template <int HW, bool SHUFFLE, bool POOL, bool RES>
+__global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(Conv3x3Args a, int nitems)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, p = lane & 31;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int tiles_x = HW / TW, tiles_y = HW / TH, tiles_img = tiles_x * tiles_y;
+    constexpr int CB = SHUFFLE ? 4 : 1;
+    const bool act = a.slope != nullptr;
+
+    const int per_xcd = nitems >> 3;                     // nitems is a multiple of 16
+    const int wg_per_xcd = (int)gridDim.x >> 3;
+    const int xcd = blockIdx.x & 7;
+    const int item_end = (xcd + 1) * per_xcd;
+    int item = xcd * per_xcd + ((int)blockIdx.x >> 3);   // < item_end: grid <= nitems
+    auto decode = [&](int it) {
+        Item r;
+        r.cb = it % CB;
+        const int tile = it / CB;
+        r.tx = tile % tiles_x;
+        r.ty = (tile / tiles_x) % tiles_y;
+        r.n = tile / tiles_img;
+        return r;
+    };
+
+    char* const ldsA = lds;
+    char* const ldsB = lds + A_BYTES;
+    float* const ldsBias = (float*)(lds + BS_OFF);
+    float* const ldsSlope = ldsBias + 4 * 96;
+
+    u32x4 stage[10];
+    auto load_a = [&](const Item& t, int c) {
+#if defined(C3_NOMEM) && (C3_NOMEM & 1)      // development: always the same (L2-resident) tile
+        const __bf16* in = (const __bf16*)a.in;
+        const int x0 = 0, y0 = 4 + 0 * t.ty;
+#else
+        const __bf16* in = (const __bf16*)a.in + (size_t)t.n * HW * HW * kC;
+        const int x0 = t.tx * TW, y0 = t.ty * TH;
+#endif
+        const int tv = opaque(tid);
+#pragma unroll
+        for (int it = 0; it < 10; ++it) {
+            const int i = tv + it * 256;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (i < A_ITEMS) {
+                const int pix = i / 6, q = i - pix * 6;
+                const int r = pix / HWP, cc = pix - r * HWP;
+                const int gy = y0 - 1 + r, gx = x0 - 1 + cc;
+                if ((unsigned)gy < (unsigned)HW && (unsigned)gx < (unsigned)HW)
+                    v = *(const u32x4*)(in + ((size_t)gy * HW + gx) * kC + c * CK + q * 8);
+            }
+            stage[it] = v;
+        }
+    };
+    auto store_a = [&]() {
+        const int tv = opaque(tid);
+#pragma unroll
+        for (int it = 0; it < 10; ++it) {
+            const int i = tv + it * 256;
+            if (i < A_ITEMS) {
+                const int pix = i / 6, q = i - pix * 6;
+                *(u32x4*)(ldsA + pix * PS + q * 16) = stage[it];
+            }
+        }
+    };
+    // async slab copy, 576 x 16 B, slab j = (tap j%9, chunk j/9) of cout block cb into ring
+    // slot j%3 (18 slabs per item, so the slot sequence continues across items)
+    auto load_b = [&](int cb, int j) {
+        const int tap = j % 9, c = j / 9;
+        const char* src = (const char*)a.wpack + ((size_t)((cb * 9 + tap) * 12 + 6 * c) * 96) * 16;
+        char* dst = ldsB + (j % NRING) * SLAB;
+        const int tv = opaque(tid);
+        glds16(src + tv * 16, dst + w * 1024);
+        glds16(src + (256 + tv) * 16, dst + (256 + w * 64) * 16);
+        if (lane < 16) glds16(src + (512 + w * 16 + (tv & 63)) * 16, dst + (512 + w * 16) * 16);
+    };
+    // Residual of this lane's outputs: pixel (y0 + w, x0 + 32*mt + p); per accumulator tile
+    // (mt, nt) two 16-byte pieces P = 0, 1 at channels 32*nt + 16*P + 8*h (see the epilogue).
+    u32x4 rres[12];
+    auto load_res = [&](const Item& t) {
+        const int lv = opaque(lane);
+        const __bf16* res = (const __bf16*)a.res +
+                            (((size_t)t.n * HW + t.ty * TH + w) * HW + t.tx * TW + (lv & 31)) * kC + 8 * (lv >> 5);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            const int mt = i / 6, nt = (i % 6) / 2, P = i % 2;
+            rres[i] = *(const u32x4*)(res + (size_t)(32 * mt) * kC + 32 * nt + 16 * P);
+        }
+    };
+
+    Item cur = decode(item);
+    load_a(cur, 0);
+    load_b(cur.cb, 0);
+    load_b(cur.cb, 1);
+    for (int i = tid; i < CB * 96; i += 256) {
+        ldsBias[i] = a.bias[i];
+        ldsSlope[i] = act ? a.slope[i] : 1.f;
+    }
+    // De-phase the two workgroups that share a CU (the first half of the grid is dealt one per
+    // CU before the second half doubles up): while one is in its epilogue / staging the other
+    // has the matrix pipe to itself.  Speed only.
+    if ((int)blockIdx.x >= ((int)gridDim.x >> 1) && gridDim.x >= 2 * 256) {
+#pragma unroll 1
+#ifndef C3_STAG
+#define C3_STAG 2
+#endif
+        for (int i = 0; i < C3_STAG; ++i) __builtin_amdgcn_s_sleep(100);
+    }
+    store_a();
+    __syncthreads();
+
+    Frags f0, f1;
+    const char* const Aw = ldsA + (w * HWP + p) * PS + h * 16;
+    const char* const Bw = ldsB + (h * 96 + p) * 16;
+
+#pragma unroll 1
+    for (;;) {
+        const int nxt = item + wg_per_xcd;
+        const bool has_next = nxt < item_end;
+        const Item nx = decode(has_next ? nxt : item);
+#ifdef SRGEN_C3_STAMPS
+        if (g_stamps && tid == 0) {
+            g_stamps[(size_t)item * 8 + 6] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_ID
+            g_stamps[(size_t)item * 8 + 7] = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // XCC_ID
+        }
+#endif
+        C3_STAMP(0);
+
+        // accumulators start at the bias (broadcast LDS reads: the address depends on h only)
+        f32x16 acc[2][3];
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+            for (int G = 0; G < 4; ++G) {
+                const f32x4 b4 = *(const f32x4*)(ldsBias + cur.cb * 96 + 32 * nt + 8 * G + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[0][nt][4 * G + e] = acc[1][nt][4 * G + e] = b4[e];
+            }
+        C3_STAMP(1);
+
+        // one ci-chunk = 9 phases (taps) x 3 k16-steps, fully unrolled; C is a compile-time chunk
+        // id so that the staging registers and the residual registers have disjoint lifetimes.
+        auto run_chunk = [&](auto C) {
+            constexpr int c = decltype(C)::value;
+            load_frags(f0, Aw, Bw + ((c * 9) % NRING) * SLAB, 0);
+#pragma unroll
+            for (int s = 0; s < 27; ++s) {
+                const int tap = s / 3, g = s % 3;
+                const int j = c * 9 + tap;
+                if (g == 0) {
+                    if (j + 2 < 18) load_b(cur.cb, j + 2);
+                    else if (has_next) load_b(nx.cb, j + 2 - 18);    // next item's slabs 0, 1
+                    if (tap == 8 && c == 0) load_a(cur, 1);
+                    if (RES && tap == 7 && c == 1) load_res(cur);
+                }
+                if (s + 1 < 27) {
+                    const int tap1 = (s + 1) / 3, g1 = (s + 1) % 3;
+                    const int dy = tap1 / 3, dx = tap1 % 3;
+                    const char* Ab = Aw + (dy * HWP + dx) * PS;
+                    const char* Bb = Bw + ((c * 9 + tap1) % NRING) * SLAB;
+                    if (s & 1) load_frags(f0, Ab, Bb, g1); else load_frags(f1, Ab, Bb, g1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (s & 1) mma_step(acc, f1); else mma_step(acc, f0);
+                if (g == 2) __syncthreads();       // slabs j+1, j+2 landed; slab j is free
+            }
+        };
+#ifdef C3_PRIO
+        __builtin_amdgcn_s_setprio(C3_PRIO);
+#endif
+        run_chunk(std::integral_constant<int, 0>{});
+        C3_STAMP(2);
+        store_a();                                // every wave is past its last read of chunk 0
+        __syncthreads();
+        C3_STAMP(3);
+        run_chunk(std::integral_constant<int, 1>{});
+        C3_STAMP(4);
+#ifdef C3_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+
+        // the A tile is free (barrier of the last phase): fetch the next item's chunk 0 into the
+        // staging registers now, its latency is covered by the epilogue arithmetic below
+        if (has_next) load_a(nx, 0);
+
+        // ---- epilogue (registers only) -----------------------------------------------------
+        // PReLU -> (+ residual) -> bf16 -> two permlane32 swaps per 16-byte piece -> NHWC stores.
+        const int y = cur.ty * TH + w, x0 = cur.tx * TW;
+        __bf16* out = (__bf16*)a.out;
+        constexpr int PXS = SHUFFLE ? 2 * kC : kC;      // element stride between this wave's pixels
+        if (SHUFFLE)
+            out += (((size_t)cur.n * 2 * HW + 2 * y + (cur.cb >> 1)) * 2 * HW + 2 * (x0 + p) + (cur.cb & 1)) * kC + 8 * h;
+        else
+            out += (((size_t)cur.n * HW + y) * HW + x0 + p) * kC + 8 * h;
+        float psum[3][16];
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) {
+            if (act) {
+#pragma unroll
+                for (int G = 0; G < 4; ++G) {
+                    const f32x4 s4 = *(const f32x4*)(ldsSlope + cur.cb * 96 + 32 * nt + 8 * G + 4 * h);
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float v = acc[mt][nt][4 * G + e];
+                            acc[mt][nt][4 * G + e] = v >= 0.f ? v : v * s4[e];
+                        }
+                }
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                f32x16& c = acc[mt][nt];
+                if (RES) {
+#pragma unroll
+                    for (int P = 0; P < 2; ++P) {
+                        const u32x4 r = rres[(mt * 3 + nt) * 2 + P];
+                        unsigned r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+                        // loaded piece = [X0 X1 Y0 Y1] in the stored (swapped) arrangement: undo it
+                        swap32(r0, r2);
+                        swap32(r1, r3);
+                        c[8 * P + 0] += bf16_lo(r0); c[8 * P + 1] += bf16_hi(r0);
+                        c[8 * P + 2] += bf16_lo(r1); c[8 * P + 3] += bf16_hi(r1);
+                        c[8 * P + 4] += bf16_lo(r2); c[8 * P + 5] += bf16_hi(r2);
+                        c[8 * P + 6] += bf16_lo(r3); c[8 * P + 7] += bf16_hi(r3);
+                    }
+                }
+                if (POOL) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) psum[nt][q] = mt == 0 ? c[q] : psum[nt][q] + c[q];
+                }
+#pragma unroll
+                for (int P = 0; P < 2; ++P) {
+                    // groups G = 2P (registers 8P..8P+3) and 2P+1 (8P+4..8P+7), 4 channels each
+                    unsigned x0d = pack_bf16(c[8 * P + 0], c[8 * P + 1]), x1d = pack_bf16(c[8 * P + 2], c[8 * P + 3]);
+                    unsigned y0d = pack_bf16(c[8 * P + 4], c[8 * P + 5]), y1d = pack_bf16(c[8 * P + 6], c[8 * P + 7]);
+                    // lanes < 32 end with [own 2P | partner's 2P] = channels 16P .. 16P+7,
+                    // lanes >= 32 with [partner's 2P+1 | own 2P+1] = channels 16P+8 .. 16P+15
+                    swap32(x0d, y0d);
+                    swap32(x1d, y1d);
+                    const u32x4 ov = {x0d, x1d, y0d, y1d};
+#if defined(C3_NOMEM) && (C3_NOMEM & 2)      // development: no output stores (kept live)
+                    if (x0d == 0x12345678u)
+#endif
+                    *(u32x4*)(out + (size_t)(32 * mt) * PXS + 32 * nt + 16 * P) = ov;
+                }
+            }
+        }
+        if (POOL) {
+            // Per-tile channel sums (ChannelAttention's pool), fixed order.  Halving butterfly over
+            // the 32 pixels of each lane half: after the 4 exchange steps lane l holds the 16-lane
+            // sum of register idx(l) = 8*l0 + 4*l1 + 2*l2 + l3 (l_i = bit i of l); one more exchange
+            // adds the other 16 lanes.  Then the 4 waves are summed through LDS (slab ring slot 2:
+            // free between the last phase and the next item's phase 0).
+            float* P = (float*)(ldsB + 2 * SLAB);
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt) {
+                float (&t)[16] = psum[nt];
+#pragma unroll
+                for (int k = 8, b = 1; k >= 1; k >>= 1, b <<= 1)
+#pragma unroll
+                    for (int i = 0; i < k; ++i) {
+                        const bool up = (lane & b) != 0;
+                        const float send = up ? t[i] : t[i + k];
+                        const float keep = up ? t[i + k] : t[i];
+                        t[i] = keep + __shfl_xor(send, b);
+                    }
+                t[0] += __shfl_xor(t[0], 16);
+                if ((lane & 16) == 0) {
+                    const int q = 8 * (lane & 1) + 4 * ((lane >> 1) & 1) + 2 * ((lane >> 2) & 1) + ((lane >> 3) & 1);
+                    P[w * kC + 32 * nt + (q & 3) + 8 * (q >> 2) + 4 * h] = t[0];
+                }
+            }
+            __syncthreads();
+            if (tid < kC) {
+                const float s = (P[tid] + P[kC + tid]) + (P[2 * kC + tid] + P[3 * kC + tid]);
+                a.pool_partial[((size_t)cur.n * tiles_img + cur.ty * tiles_x + cur.tx) * kC + tid] = s;
+            }
+        }
+        C3_STAMP(5);
+        if (!has_next) break;
+        store_a();
+        __syncthreads();                          // next A chunk 0 and its slabs 0, 1 are in LDS
+        item = nxt;
+        cur = nx;
+    }
+}
+
+template <int HW, bool SHUFFLE, bool POOL, bool RES>
+hipError_t launch_one(const Conv3x3Args& a, hipStream_t s)
+{
+    static bool attr_set[64] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+        e = hipFuncSetAttribute((const void*)conv3x3_bf16_kernel<HW, SHUFFLE, POOL, RES>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    }
+    const int nitems = a.N * (HW / TH) * (HW / TW) * (SHUFFLE ? 4 : 1);     // multiple of 16
+    const int grid = nitems < MAX_WGS ? nitems & ~7 : MAX_WGS;
+    hipLaunchKernelGGL((conv3x3_bf16_kernel<HW, SHUFFLE, POOL, RES>), dim3((unsigned)grid), dim3(256), LDS_BYTES,
+                       s, a, nitems);
+    return hipGetLastError();
+}
+
+}  // namespace c3
+
+hipError_t launch_conv3x3_bf16(const Conv3x3Args& a, hipStream_t s)
+{
+    using namespace c3;
+    if (a.H != a.W || a.N <= 0) return hipErrorInvalidValue;
+    const bool res = a.res != nullptr, pool = a.pool_partial != nullptr;
+    if (a.H == kLR && !a.shuffle && a.cout_blocks == 1) {
+        if (!pool && !res) return launch_one<kLR, false, false, false>(a, s);
+        if (!pool && res) return launch_one<kLR, false, false, true>(a, s);
+        if (pool && res) return launch_one<kLR, false, true, true>(a, s);
+    }
+    if (a.H == kLR && a.shuffle && a.cout_blocks == 4 && !pool && !res) return launch_one<kLR, true, false, false>(a, s);
+    if (a.H == kHR && !a.shuffle && a.cout_blocks == 1 && !pool && !res) return launch_one<kHR, false, false, false>(a, s);
+    return hipErrorInvalidValue;
+}
+
+}  // namespace srgen
