@@ -43,6 +43,29 @@ __global__ __launch_bounds__(256) void k(const bf16x8* in, float* out, long long
     if (tid == 0) ticks[blockIdx.x] = t1 - t0;
 }
 
+__global__ __launch_bounds__(256) void kf32(const float* in, float* out, long long* ticks, int iters)
+{
+    const int tid = threadIdx.x;
+    float a0 = in[tid], a1 = in[tid + 256], b0 = in[tid + 512], b1 = in[tid + 768], b2 = in[tid + 1024];
+    f32x16 c[6];
+    for (int i = 0; i < 6; ++i) for (int r = 0; r < 16; ++r) c[i][r] = 0.f;
+    __syncthreads();
+    const long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+        c[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0, a0, c[0], 0, 0, 0);
+        c[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0, a1, c[1], 0, 0, 0);
+        c[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1, a0, c[2], 0, 0, 0);
+        c[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1, a1, c[3], 0, 0, 0);
+        c[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(b2, a0, c[4], 0, 0, 0);
+        c[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(b2, a1, c[5], 0, 0, 0);
+    }
+    const long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0;
+    for (int i = 0; i < 6; ++i) for (int r = 0; r < 16; ++r) s += c[i][r];
+    out[blockIdx.x * 256 + tid] = s;
+    if (tid == 0) ticks[blockIdx.x] = t1 - t0;
+}
+
 int main()
 {
     bf16x8* in; float* out; long long* ticks;
@@ -69,5 +92,20 @@ int main()
             printf("shape %dx%d  %4d WGs (%.0f waves/SIMD): median %.1f ticks/MFMA per wave, %.3f ms, %.0f TFLOP/s, clock~%.2f GHz\n",
                    shape, shape, wgs, wgs / 256.0, t[wgs / 2] / nm, ms, flop / ms * 1e-9, t[wgs/2] / (ms * 1e6) * (wgs > 512 ? 0.5 : 1.0));
         }
+    for (int wgs : {256, 512}) {
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        for (int rep = 0; rep < 2; ++rep) {
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(kf32, dim3(wgs), dim3(256), 0, 0, (const float*)in, out, ticks, iters);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+        }
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        std::vector<long long> t(wgs);
+        hipMemcpy(t.data(), ticks, wgs * 8, hipMemcpyDeviceToHost);
+        std::sort(t.begin(), t.end());
+        const double nm = 6.0 * iters, flop = (double)wgs * 4 * nm * 4096.0;
+        printf("f32 32x32x2  %4d WGs: median %.1f ticks/MFMA per wave, %.3f ms, %.1f TFLOP/s, clock~%.2f GHz\n", wgs,
+               t[wgs / 2] / nm, ms, flop / ms * 1e-9, t[wgs / 2] / (ms * 1e6));
+    }
     return 0;
 }
