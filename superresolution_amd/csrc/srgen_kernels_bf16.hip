@@ -245,7 +245,11 @@ __global__ __launch_bounds__(256, 2) void head_bf16_kernel(HeadArgs a)
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, p = lane & 31;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ty = blockIdx.x % (kHR / 4), n = blockIdx.x / (kHR / 4);
+    // XCD-aware mapping: ids b, b+8, ... share an XCD (private L2); give each XCD a contiguous run
+    // of row blocks so the 8 halo rows two neighbouring blocks share are L2 hits
+    const int nblk = gridDim.x;
+    const int blk = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
+    const int ty = blk % (kHR / 4), n = blk / (kHR / 4);
     const int y0 = ty * 4;
     const __bf16* in = (const __bf16*)a.in + (size_t)n * kHR * kHR * kC;
     const bf16x8* wp = (const bf16x8*)a.wpack;
@@ -256,24 +260,63 @@ __global__ __launch_bounds__(256, 2) void head_bf16_kernel(HeadArgs a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
 
-    for (int g = 0; g < 6; ++g) {
-        __syncthreads();
-        for (int i = tid; i < HB_ROWS * HB_COLS * 2; i += 256) {
-            const int half = i & 1, pix = i >> 1;
+    // 12 x 160 pixel halo tile of one 16-ci chunk = 3,840 16-byte pieces, 15 per thread.  The
+    // loads are branch-free (clamped address + a validity bit applied at the LDS store) and are
+    // issued one chunk ahead, so their latency sits under the previous chunk's MFMAs.
+    u32x4 stage[15];
+    unsigned ok_bits = 0;
+#pragma unroll
+    for (int it = 0; it < 15; ++it) {
+        const int i = tid + it * 256, pix = i >> 1;
+        const int r = pix / HB_COLS, c = pix - r * HB_COLS;
+        const int gy = y0 - 4 + r, gx = c - 4;
+        ok_bits |= (((unsigned)gy < (unsigned)kHR && (unsigned)gx < (unsigned)kHR) ? 1u : 0u) << it;
+    }
+    auto load_stage = [&](int g) {
+#pragma unroll
+        for (int it = 0; it < 15; ++it) {
+            const int i = tid + it * 256, half = i & 1, pix = i >> 1;
             const int r = pix / HB_COLS, c = pix - r * HB_COLS;
-            const int gy = y0 - 4 + r, gx = c - 4;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if ((unsigned)gy < (unsigned)kHR && (unsigned)gx < (unsigned)kHR)
-                v = *(const u32x4*)(in + ((size_t)gy * kHR + gx) * kC + g * 16 + half * 8);
+            const int cy = min(max(y0 - 4 + r, 0), kHR - 1), cx = min(max(c - 4, 0), kHR - 1);
+            stage[it] = *(const u32x4*)(in + ((size_t)cy * kHR + cx) * kC + g * 16 + half * 8);
+        }
+    };
+    auto store_stage = [&]() {
+#pragma unroll
+        for (int it = 0; it < 15; ++it) {
+            const int i = tid + it * 256, half = i & 1, pix = i >> 1;
+            u32x4 v = stage[it];
+            if (!((ok_bits >> it) & 1u)) v = u32x4{0u, 0u, 0u, 0u};
             *(u32x4*)(lds + half * HB_PLANE + pix * 16) = v;
         }
+    };
+
+    load_stage(0);
+#pragma unroll 1
+    for (int g = 0; g < 6; ++g) {
+        __syncthreads();                          // every wave is past its reads of chunk g-1
+        bf16x8 bv[9];
+#pragma unroll
+        for (int ky = 0; ky < 9; ++ky) bv[ky] = wp[((ky * 6 + g) * 2 + h) * 32 + p];
+        store_stage();
         __syncthreads();
+        if (g + 1 < 6) load_stage(g + 1);
+        const char* ab = lds + h * HB_PLANE + (w * HB_COLS + p) * 16;
+        bf16x8 a0[5], a1[5];
+#pragma unroll
+        for (int mt = 0; mt < 5; ++mt) a0[mt] = *(const bf16x8*)(ab + 32 * 16 * mt);
 #pragma unroll
         for (int ky = 0; ky < 9; ++ky) {
-            const bf16x8 bv = wp[((ky * 6 + g) * 2 + h) * 32 + p];
-            const char* ab = lds + h * HB_PLANE + ((w + ky) * HB_COLS + p) * 16;
+            if (ky + 1 < 9) {
 #pragma unroll
-            for (int mt = 0; mt < 5; ++mt) acc[mt] = MFMA_BF16(*(const bf16x8*)(ab + 32 * 16 * mt), bv, acc[mt]);
+                for (int mt = 0; mt < 5; ++mt) {
+                    const bf16x8 v = *(const bf16x8*)(ab + ((ky + 1) * HB_COLS + 32 * mt) * 16);
+                    if (ky & 1) a0[mt] = v; else a1[mt] = v;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mt = 0; mt < 5; ++mt) acc[mt] = MFMA_BF16((ky & 1) ? a1[mt] : a0[mt], bv[ky], acc[mt]);
         }
     }
     __syncthreads();

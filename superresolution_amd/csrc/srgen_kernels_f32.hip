@@ -185,8 +185,13 @@ constexpr int TH_LDS_BYTES = 4 * TH_COLS * TH_TS * 4;   // 74,240 >= 4*TH_PLANE*
 __global__ __launch_bounds__(256, 2) void head_f32_kernel(HeadArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, p = lane & 31;
-    const int ty = blockIdx.x % (kHR / 4), n = blockIdx.x / (kHR / 4);
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, p = lane & 31;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // XCD-aware mapping: each XCD (private L2) gets a contiguous run of row blocks, so the 8 halo
+    // rows two neighbouring blocks share are L2 hits
+    const int nblk = gridDim.x;
+    const int blk = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
+    const int ty = blk % (kHR / 4), n = blk / (kHR / 4);
     const int y0 = ty * 4;
     const float* in = (const float*)a.in + (size_t)n * kHR * kHR * kC;
     const f32x2* wp = (const f32x2*)a.wpack;
@@ -197,35 +202,71 @@ __global__ __launch_bounds__(256, 2) void head_f32_kernel(HeadArgs a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
 
-    for (int c8 = 0; c8 < 12; ++c8) {
-        __syncthreads();
-        // stage 12 x 160 pixels x 8 ci: each item = one pixel's half (4 ci = 2 planes)
-        for (int i = tid; i < TH_ROWS * TH_COLS * 2; i += 256) {
-            const int half = i & 1, pix = i >> 1;
+    // 12 x 160 pixels x 8 ci per chunk = 3,840 16-byte pieces, 15 per thread; branch-free loads
+    // (clamped address, validity bit applied at the LDS store) issued one chunk ahead.
+    f32x4 stage[15];
+    unsigned ok_bits = 0;
+#pragma unroll
+    for (int it = 0; it < 15; ++it) {
+        const int i = tid + it * 256, pix = i >> 1;
+        const int r = pix / TH_COLS, c = pix - r * TH_COLS;
+        const int gy = y0 - 4 + r, gx = c - 4;
+        ok_bits |= (((unsigned)gy < (unsigned)kHR && (unsigned)gx < (unsigned)kHR) ? 1u : 0u) << it;
+    }
+    auto load_stage = [&](int c8) {
+#pragma unroll
+        for (int it = 0; it < 15; ++it) {
+            const int i = tid + it * 256, half = i & 1, pix = i >> 1;
             const int r = pix / TH_COLS, c = pix - r * TH_COLS;
-            const int gy = y0 - 4 + r, gx = c - 4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if ((unsigned)gy < (unsigned)kHR && (unsigned)gx < (unsigned)kHR)
-                v = *(const f32x4*)(in + ((size_t)gy * kHR + gx) * kC + c8 * 8 + half * 4);
-            f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
+            const int cy = min(max(y0 - 4 + r, 0), kHR - 1), cx = min(max(c - 4, 0), kHR - 1);
+            stage[it] = *(const f32x4*)(in + ((size_t)cy * kHR + cx) * kC + c8 * 8 + half * 4);
+        }
+    };
+    auto store_stage = [&]() {
+#pragma unroll
+        for (int it = 0; it < 15; ++it) {
+            const int i = tid + it * 256, half = i & 1, pix = i >> 1;
+            f32x4 v = stage[it];
+            if (!((ok_bits >> it) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
             *(f32x2*)(smem + (2 * half) * TH_PLANE + pix * 2) = lo;
             *(f32x2*)(smem + (2 * half + 1) * TH_PLANE + pix * 2) = hi;
         }
+    };
+
+    load_stage(0);
+#pragma unroll 1
+    for (int c8 = 0; c8 < 12; ++c8) {
+        __syncthreads();                          // every wave is past its reads of chunk c8-1
+        f32x2 bv[18];
+#pragma unroll
+        for (int s = 0; s < 18; ++s) bv[s] = wp[((((size_t)(s >> 1) * 12 + c8) * 2 + (s & 1)) * 2 + h) * 32 + p];
+        store_stage();
         __syncthreads();
+        if (c8 + 1 < 12) load_stage(c8 + 1);
+        f32x2 a0[5], a1[5];
+        {
+            const float* ab = smem + h * TH_PLANE + (w * TH_COLS + p) * 2;
 #pragma unroll
-        for (int ky = 0; ky < 9; ++ky) {
+            for (int mt = 0; mt < 5; ++mt) a0[mt] = *(const f32x2*)(ab + 64 * mt);
+        }
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const f32x2 bv = wp[((((size_t)ky * 12 + c8) * 2 + u) * 2 + h) * 32 + p];
+        for (int s = 0; s < 18; ++s) {                // s = ky*2 + u
+            if (s + 1 < 18) {
+                const int ky = (s + 1) >> 1, u = (s + 1) & 1;
                 const float* ab = smem + (2 * u + h) * TH_PLANE + ((w + ky) * TH_COLS + p) * 2;
-                f32x2 av[5];
 #pragma unroll
-                for (int mt = 0; mt < 5; ++mt) av[mt] = *(const f32x2*)(ab + 64 * mt);
-#pragma unroll
-                for (int e = 0; e < 2; ++e)
-#pragma unroll
-                    for (int mt = 0; mt < 5; ++mt) acc[mt] = MFMA_F32(av[mt][e], bv[e], acc[mt]);
+                for (int mt = 0; mt < 5; ++mt) {
+                    const f32x2 v = *(const f32x2*)(ab + 64 * mt);
+                    if (s & 1) a0[mt] = v; else a1[mt] = v;
+                }
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int mt = 0; mt < 5; ++mt)
+                    acc[mt] = MFMA_F32((s & 1) ? a1[mt][e] : a0[mt][e], bv[s][e], acc[mt]);
         }
     }
     __syncthreads();
