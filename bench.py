@@ -11,10 +11,13 @@ data-path collective); the only collective is the metric all-reduce of evaluate(
 timed forward.  Rank 0 prints ONE JSON line.
 
 Extra objects on that line:
-  roofline      dominant kernel = conv3x3_f32_kernel<64,false> (the 33 trunk 3x3 convs, 75 % of the
-                FLOPs).  achieved = algorithmic FLOPs per launch (2*4096*96*864 per image x batch)
-                / average launch duration measured live with HIP events on the launch stream
-                (srgen_forward_profile); peak = 157.3 TFLOP/s fp32 matrix (MI355X_MICROARCH.md).
+  roofline      dominant kernel = conv3x3_<dtype>_kernel<64, ...> (the 33 trunk 3x3 convs, 75 % of
+                the FLOPs).  achieved = algorithmic FLOPs per launch (2*4096*96*864 per image x
+                batch) / average launch duration measured live with HIP events on the launch
+                stream (srgen_forward_profile); peak = 157.3 TFLOP/s fp32 matrix / 2500 TFLOP/s
+                bf16 dense (MI355X_MICROARCH.md); traffic = HBM bytes per launch from the committed
+                rocprofv3 PMC summary (profiles/traffic_<dtype>.json, tools/summarize_profiles.py:
+                FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate --pmc passes).
   cpu_baseline  the reference's forward restated with stock torch CPU ops (oracle/torch_ref.py,
                 kind "port": same ATen conv kernels the reference dispatches) on the box's host
                 cores, batch 16, bounded to ~10-20 s.
@@ -127,7 +130,7 @@ def main():
                 traffic = json.load(open(tpath)).get("conv3x3_trunk_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        roof = {"bound": "mfma", "kernel": f"conv3x3_{args.dtype}_kernel<64,false>",
+        roof = {"bound": "mfma", "kernel": f"conv3x3_{args.dtype}_kernel<64,false,*,*> (33 trunk launches)",
                 "achieved": round(achieved, 2), "peak": PEAK[args.dtype], "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK[args.dtype], 4), "traffic": traffic,
                 "ms_per_launch": round(ms_launch, 4),
