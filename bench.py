@@ -76,8 +76,12 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or bool(os.environ.get("SRGEN_BENCH_FORCE_DIST"))   # the latter: 1-rank rehearsal
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     g = Generator()
@@ -90,7 +94,7 @@ def main():
         x = x.to(torch.bfloat16)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -102,7 +106,7 @@ def main():
         y = g(x)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -136,6 +140,32 @@ def main():
                 "ms_per_launch": round(ms_launch, 4),
                 "flop_per_launch": TRUNK_CONV_FLOP_PER_IMAGE * args.batch}
 
+    # ---- HBM-bound kernels of the path: achieved GB/s against the 8 TB/s HBM3E peak ------------
+    hbm = {}
+    if rank == 0:
+        elt = 2 if args.dtype == "bf16" else 4
+        ca_bytes = 2 * args.batch * 64 * 64 * 96 * elt          # one read + one write (pool fused upstream)
+        ca_ms = kernels["chan_attn"]["ms_per_launch"]
+        hbm["chan_attn"] = {"algorithmic_bytes": ca_bytes, "ms_per_launch": ca_ms,
+                            "GBps": round(ca_bytes / (ca_ms * 1e-3) / 1e9, 1),
+                            "frac_of_8TBps": round(ca_bytes / (ca_ms * 1e-3) / 8e12, 3)}
+        from superresolution_amd import bilinear_resize
+        z = torch.rand((args.batch, 3, 128, 128), device=dev)
+        for _ in range(3):
+            bilinear_resize(z, (125, 125))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()                                              # the op launches on torch's current stream
+        for _ in range(20):
+            bilinear_resize(z, (125, 125))
+        e1.record()
+        e1.synchronize()
+        rs_ms = e0.elapsed_time(e1) / 20
+        rs_bytes = args.batch * 3 * (128 * 128 + 125 * 125) * 4
+        hbm["bilinear_resize_128_to_125"] = {"algorithmic_bytes": rs_bytes, "ms_per_launch": round(rs_ms, 4),
+                                             "GBps": round(rs_bytes / (rs_ms * 1e-3) / 1e9, 1),
+                                             "frac_of_8TBps": round(rs_bytes / (rs_ms * 1e-3) / 8e12, 3),
+                                             "note": "optional op, not on the forward path (the reference crops)"}
+
     if rank == 0:
         imgs = args.batch * world * args.steps
         value = imgs / dt
@@ -150,12 +180,12 @@ def main():
                        "parallelism": f"batch-sharded x{world}, weights replicated"},
             "end_to_end_tflops": round(value * FLOP_PER_IMAGE / 1e12, 2),
             "end_to_end_frac_of_peak": round(value / world * FLOP_PER_IMAGE / 1e12 / PEAK[args.dtype], 4),
-            "roofline": roof, "kernels": kernels,
+            "roofline": roof, "kernels": kernels, "hbm_kernels": hbm,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

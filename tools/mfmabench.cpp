@@ -8,6 +8,30 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+__global__ __launch_bounds__(256) void k16(const bf16x8* in, float* out, long long* ticks, int iters)
+{
+    const int tid = threadIdx.x;
+    bf16x8 a[4], b[6];
+    for (int i = 0; i < 4; ++i) a[i] = in[tid + 256 * i];
+    for (int i = 0; i < 6; ++i) b[i] = in[tid + 256 * (i % 5)];
+    f32x4 c[24];
+    for (int i = 0; i < 24; ++i) c[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    const long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int m = 0; m < 6; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                c[m * 4 + n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[m], a[n], c[m * 4 + n], 0, 0, 0);
+    }
+    const long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0;
+    for (int i = 0; i < 24; ++i) s += c[i][0] + c[i][1] + c[i][2] + c[i][3];
+    out[blockIdx.x * 256 + tid] = s;
+    if (tid == 0) ticks[blockIdx.x] = t1 - t0;
+}
+
 template <int SHAPE>
 __global__ __launch_bounds__(256) void k(const bf16x8* in, float* out, long long* ticks, int iters)
 {
@@ -80,14 +104,14 @@ int main()
             for (int rep = 0; rep < 2; ++rep) {
                 hipEventRecord(e0);
                 if (shape == 32) hipLaunchKernelGGL(k<32>, dim3(wgs), dim3(256), 0, 0, in, out, ticks, iters);
-                else hipLaunchKernelGGL(k<16>, dim3(wgs), dim3(256), 0, 0, in, out, ticks, iters);
+                else hipLaunchKernelGGL(k16, dim3(wgs), dim3(256), 0, 0, in, out, ticks, iters / 2);
                 hipEventRecord(e1); hipEventSynchronize(e1);
             }
             float ms; hipEventElapsedTime(&ms, e0, e1);
             std::vector<long long> t(wgs);
             hipMemcpy(t.data(), ticks, wgs * 8, hipMemcpyDeviceToHost);
             std::sort(t.begin(), t.end());
-            const double nm = shape == 32 ? 6.0 * iters : 24.0 * iters;
+            const double nm = shape == 32 ? 6.0 * iters : 24.0 * (iters / 2);
             const double flop = (double)wgs * 4 * nm * (shape == 32 ? 32768.0 : 16384.0);
             printf("shape %dx%d  %4d WGs (%.0f waves/SIMD): median %.1f ticks/MFMA per wave, %.3f ms, %.0f TFLOP/s, clock~%.2f GHz\n",
                    shape, shape, wgs, wgs / 256.0, t[wgs / 2] / nm, ms, flop / ms * 1e-9, t[wgs/2] / (ms * 1e6) * (wgs > 512 ? 0.5 : 1.0));
