@@ -129,6 +129,13 @@ SRGEN_API int srgen_forward_profile(srgen_handle* h, const void* x, void* y, voi
 SRGEN_API int srgen_bilinear_resize(const float* x, float* y, int planes, int h, int w, int oh, int ow,
                           void* stream);
 
+/* Replaces: the input normalisation of JetImageDataset.__iter__ (dataset.py:52-54),
+ * torch.clamp(t / hr_max, 0, 1) with hr_max = normalization_stats.pt['hr_p995'] (train.py:234),
+ * moved from the DataLoader workers' CPU to the device: raw chunk -> H2D -> this -> generator.
+ * x: device fp32, numel elements; y: device, fp32 (SRGEN_F32) or bf16 (SRGEN_BF16), may alias x
+ * only for SRGEN_F32.  True fp32 division: bit-identical to the reference expression. */
+SRGEN_API int srgen_normalize(const float* x, void* y, size_t numel, float hr_max, int out_dtype, void* stream);
+
 /* Replaces: utils.psnr / utils.ssim / nn.L1Loss as called per batch by validate()
  * (train.py:66-68; utils.py:5-41).  sr, hr: device (n, 3, hgt, wid) NCHW fp32.
  * out3: device, 3 floats {psnr, ssim, l1} for the whole batch -- stays on the device so the

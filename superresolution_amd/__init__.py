@@ -6,6 +6,7 @@
 from .generator import Generator, ResBlock, ChannelAttention, UpsampleBlock  # noqa: F401
 from .functional import bilinear_resize, batch_metrics  # noqa: F401
 from . import weights  # noqa: F401
+from . import data  # noqa: F401
 
 __all__ = ["Generator", "ResBlock", "ChannelAttention", "UpsampleBlock", "bilinear_resize", "batch_metrics",
-           "weights"]
+           "weights", "data"]

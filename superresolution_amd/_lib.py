@@ -60,10 +60,11 @@ def lib() -> ctypes.CDLL:
     L.srgen_forward_profile.argtypes = [vp, vp, vp, vp, sz, i, i, vp, ctypes.POINTER(ctypes.c_float),
                                         ctypes.POINTER(ctypes.c_int)]
     L.srgen_bilinear_resize.argtypes = [vp, vp, i, i, i, i, i, vp]
+    L.srgen_normalize.argtypes = [vp, vp, sz, ctypes.c_float, i, vp]
     L.srgen_metrics_scratch_bytes.argtypes = [i, i, i, i, ctypes.POINTER(sz)]
     L.srgen_metrics.argtypes = [vp, vp, i, i, i, i, vp, vp, sz, vp]
     for name in ("srgen_create", "srgen_destroy", "srgen_set_tensor", "srgen_commit_weights",
-                 "srgen_workspace_bytes", "srgen_forward", "srgen_forward_taps", "srgen_forward_profile", "srgen_bilinear_resize",
+                 "srgen_workspace_bytes", "srgen_forward", "srgen_forward_taps", "srgen_forward_profile", "srgen_bilinear_resize", "srgen_normalize",
                  "srgen_metrics_scratch_bytes", "srgen_metrics"):
         getattr(L, name).restype = i
     if L.srgen_abi_version() != 1:

@@ -631,6 +631,16 @@ int srgen_bilinear_resize(const float* x, float* y, int planes, int hgt, int wid
     return SRGEN_OK;
 }
 
+int srgen_normalize(const float* x, void* y, size_t numel, float hr_max, int out_dtype, void* stream)
+{
+    if (out_dtype != SRGEN_F32 && out_dtype != SRGEN_BF16) return fail(SRGEN_E_INVALID, "unknown dtype %d", out_dtype);
+    if (numel == 0) return SRGEN_OK;
+    if (!x || !y) return fail(SRGEN_E_INVALID, "x or y is NULL");
+    if (((uintptr_t)x & 15) || ((uintptr_t)y & 15)) return fail(SRGEN_E_INVALID, "x and y must be 16-byte aligned");
+    HIP_TRY(launch_normalize(x, y, numel, hr_max, out_dtype == SRGEN_BF16, (hipStream_t)stream));
+    return SRGEN_OK;
+}
+
 int srgen_metrics_scratch_bytes(int n, int c, int hgt, int wid, size_t* bytes)
 {
     if (!bytes || n <= 0 || c <= 0 || hgt <= 0 || wid <= 0) return fail(SRGEN_E_INVALID, "bad metrics shape");

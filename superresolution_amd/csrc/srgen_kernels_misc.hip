@@ -40,6 +40,55 @@ hipError_t launch_nhwc_to_nchw_f32(const void* in, int in_is_bf16, float* out, i
     return hipGetLastError();
 }
 
+// ---- input normalisation: clamp(x / hr_max, 0, 1) -- dataset.py:52-54 -------------------------
+// The division is a true IEEE fp32 division (not a multiply by the reciprocal), so the result is
+// bit-identical to torch.clamp(x / hr_max, 0, 1).  HBM-bound: 16 bytes per lane in, 16 (fp32) or
+// 8 (bf16) bytes out; the tail (numel % 4) is handled by the last lanes one element at a time.
+typedef float nf32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float norm1(float v, float hr_max)
+{
+    // torch.clamp(v / hr_max, 0, 1) = min(max(q, 0), 1); NaN propagates as in ATen
+    const float q = __fdiv_rn(v, hr_max);
+    const float lo = q < 0.f ? 0.f : q;
+    return lo > 1.f ? 1.f : lo;
+}
+
+template <bool BF16_OUT>
+__global__ __launch_bounds__(256) void normalize_kernel(const float* __restrict__ x, void* __restrict__ y,
+                                                        size_t numel, float hr_max)
+{
+    const size_t n4 = numel / 4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const nf32x4 v = ((const nf32x4*)x)[i];
+        const float r0 = norm1(v.x, hr_max), r1 = norm1(v.y, hr_max), r2 = norm1(v.z, hr_max), r3 = norm1(v.w, hr_max);
+        if (BF16_OUT) {
+            typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+            const bf16x4 o = {(__bf16)r0, (__bf16)r1, (__bf16)r2, (__bf16)r3};
+            ((bf16x4*)y)[i] = o;
+        } else {
+            const nf32x4 o = {r0, r1, r2, r3};
+            ((nf32x4*)y)[i] = o;
+        }
+    }
+    const size_t tail = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (tail < numel) {
+        const float r = norm1(x[tail], hr_max);
+        if (BF16_OUT) ((__bf16*)y)[tail] = (__bf16)r;
+        else ((float*)y)[tail] = r;
+    }
+}
+
+hipError_t launch_normalize(const float* x, void* y, size_t numel, float hr_max, int out_bf16, hipStream_t s)
+{
+    size_t blocks = (numel / 4 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 256 * 32) blocks = 256 * 32;            // grid-stride beyond 32 blocks per CU
+    if (out_bf16) hipLaunchKernelGGL(normalize_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, x, y, numel, hr_max);
+    else hipLaunchKernelGGL(normalize_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, x, y, numel, hr_max);
+    return hipGetLastError();
+}
+
 // ---- bilinear resize, align_corners=False (ATen upsample_bilinear2d semantics) --------------
 // src = max(0, (dst + 0.5) * in/out - 0.5); i0 = floor(src); i1 = i0 + (i0 < in-1); l = src - i0.
 // One thread per output pixel, consecutive lanes -> consecutive ox: coalesced stores, and the

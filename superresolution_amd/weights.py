@@ -163,3 +163,26 @@ def synthetic_hr_batch(n: int, seed: int = 1, in_ch: int = 3, hw: int = 125) -> 
     """(n, in_ch, hw, hw) fp32 U[0,1) target used only to form PSNR/SSIM numbers."""
     m = n * in_ch * hw * hw
     return hash_uniform(seed, "hr.dense", m).astype(np.float32).reshape(n, in_ch, hw, hw)
+
+
+def write_synthetic_chunks(tensor_dir: str, num_files: int = 10, seed: int = 5):
+    """Writes `num_files` chunk files in the reference's format (scripts/convert_to_pt.py:39:
+    {'lr','hr','num_samples'}) plus normalization_stats.pt, deterministically from the integer
+    hash: sparse non-negative "jet image" values with a long tail, ragged sample counts (3..6),
+    down-sized hr (3,25,25) so the fixture stays small -- the dataset logic does not look at
+    spatial shapes.  Used by tests/golden/make_golden.py (to run the real reference dataset over
+    them) and by the tests (to run the mirror over the same bytes)."""
+    import os
+    import torch
+    os.makedirs(tensor_dir, exist_ok=True)
+    for f in range(num_files):
+        n = 3 + (f * 7 + seed) % 4
+        lr = hash_uniform(seed, f"chunk{f}.lr", n * 3 * 64 * 64).reshape(n, 3, 64, 64)
+        hr = hash_uniform(seed, f"chunk{f}.hr", n * 3 * 25 * 25).reshape(n, 3, 25, 25)
+        # ~90 % zeros, the rest up to ~3x the p99.5 scale so the clamp at 1 is exercised
+        lr = np.where(lr > 0.9, (lr - 0.9) * 30.0, 0.0).astype(np.float32)
+        hr = np.where(hr > 0.9, (hr - 0.9) * 30.0, 0.0).astype(np.float32)
+        torch.save({"lr": torch.from_numpy(lr), "hr": torch.from_numpy(hr), "num_samples": n},
+                   os.path.join(tensor_dir, f"synthetic_run{f // 4}_chunk{f % 4:03d}.pt"))
+    torch.save({"lr_max": 3.0, "hr_max": 3.0, "lr_p995": 1.25, "hr_p995": 1.37},
+               os.path.join(tensor_dir, "normalization_stats.pt"))

@@ -24,6 +24,10 @@ Fixtures written:
   pixel_shuffle.npz    integer ramp through nn.PixelShuffle(2): exact permutation KAT
   discriminator.npz    Discriminator default-init output + RelativisticAverageLoss values
                        (for the "next" rows)
+  dataset.npz          the reference JetImageDataset (dataset.py) iterated over the synthetic chunk
+                       files of weights.write_synthetic_chunks: per-sample (sum lr, sum hr, max)
+                       in yield order for the train / val / test splits (num_workers = 0) and the
+                       per-batch sums of a DataLoader(batch_size=4, num_workers=2) over train
 """
 import importlib.util
 import os
@@ -76,6 +80,33 @@ def run_with_taps(gen, x):
     for h in hooks:
         h.remove()
     return y, taps
+
+
+def make_dataset_golden():
+    # ---- dataset.py over synthetic chunks ------------------------------------------------
+    import tempfile
+    from torch.utils.data import DataLoader
+    from superresolution_amd import weights as W
+    ds_mod = load_ref("ref_dataset", "dataset.py")
+    ds = {}
+    with tempfile.TemporaryDirectory() as td:
+        W.write_synthetic_chunks(td)
+        hr_max = torch.load(os.path.join(td, "normalization_stats.pt"))["hr_p995"]
+        ds["hr_p995"] = np.float64(hr_max)
+        for split in ("train", "val", "test"):
+            d = ds_mod.JetImageDataset(td, split=split, hr_max=hr_max)
+            rows = [(float(lr.double().sum()), float(hr.double().sum()), float(lr.max()), float(hr.max()))
+                    for lr, hr in d]
+            ds[f"{split}_rows"] = np.array(rows, np.float64).reshape(-1, 4)
+            ds[f"{split}_nfiles"] = np.int64(len(d.files))
+        d = ds_mod.JetImageDataset(td, split="train", hr_max=hr_max)
+        rows = [(float(lr.double().sum()), float(hr.double().sum()), lr.shape[0])
+                for lr, hr in DataLoader(d, batch_size=4, num_workers=2)]
+        ds["train_loader_w2_b4"] = np.array(rows, np.float64)
+        d = ds_mod.JetImageDataset(td, split="train", hr_max=None)
+        ds["train_raw_rows"] = np.array([(float(lr.double().sum()), float(hr.double().sum())) for lr, hr in d],
+                                        np.float64)
+    np.savez_compressed(os.path.join(OUT, "dataset.npz"), **ds)
 
 
 def main():
@@ -169,8 +200,13 @@ def main():
     dd["loss_d"] = np.array(crit.discriminator_loss(dr, df).item())
     dd["loss_g"] = np.array(crit.generator_loss(dr, df).item())
     np.savez_compressed(os.path.join(OUT, "discriminator.npz"), **dd)
+
+    make_dataset_golden()
     print("discriminator: params", dd["n_params"], "out", dd["out_shape"])
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "dataset":
+        make_dataset_golden()      # only tests/golden/dataset.npz
+    else:
+        main()
