@@ -1,0 +1,372 @@
+// srgen_conv3x3_f32_wino.hip -- gfx950 fp32 3x3 conv 96 -> 96 (x cout_blocks) as Winograd
+// F(2x2, 3x3) on the exact-fp32 matrix instruction v_mfma_f32_16x16x4_f32.
+//
+// Reference sites (file:line into /root/reference): Generator.py:34,37 (ResBlock convs; eval
+// BatchNorm :35,38 and the 0.1 of :42 folded into w, b on the host), :62 (mid), :7 (upsample
+// conv, PixelShuffle :8 folded into the store address), :69 (output[0]); PReLU :36,:9,:70 and
+// the residual adds :42,:78 are the epilogue.
+//
+// Why: the fp32 direct kernel (srgen_conv3x3_f32.hip) already runs at 93 % of what the matrix
+// pipe delivers on this part, so the only lever left is fewer matrix FLOPs.  For a 2x2 output
+// tile, Y = At [ (G g Gt) . (Bt d B) ] A needs 16 multiplies per (ci, co) instead of 36: the 16
+// element-wise products, summed over ci, are 16 independent GEMMs
+//     M[xi][nu][co][tile] = sum_ci U[xi][nu][co][ci] * V[xi][nu][ci][tile]
+// with U = G g Gt precomputed on the host (fp64, rounded once) and V = Bt d B formed on the fly.
+// All transform coefficients are 0, +-1, +-1/2: no precision-critical constants.  Error against
+// the fp64 oracle stays ~1e-6 of max|ref| per conv (tests: <= 1e-4 end to end).
+//
+// Mapping (one persistent workgroup of 4 waves per CU, one wave per SIMD):
+//   * work item = 4 output rows x 64 pixels = 2 tile-rows x 32 tiles, x 96 co; wave w owns 16
+//     tiles: tile-row (w >> 1), tiles 16*(w & 1) + (lane & 15).  The MFMA's A operand is U
+//     (rows = co), its B operand is V (columns = tiles), so accumulator register r of lane l is
+//     C[co = 16*mt + 4*(l >> 4) + r][tile = l & 15]: 4 consecutive channels of one tile, and the
+//     output transform + epilogue are registers only;
+//   * loop nest: nu (4) > ci chunk of 16 (6) > xi (4) > 24 MFMAs (4 k-steps x 6 co blocks).  For
+//     a fixed nu only the four M[xi][nu] (96 registers) are live; after the last chunk they are
+//     folded into the 2x2 output accumulators y[i][j] (96 registers): T_i = sum_xi At[i][xi]
+//     M[xi][nu], y[i][j] += At[j][nu] T_i.  The input chunks are therefore re-staged once per nu
+//     (4x the L2 -> LDS traffic of the direct kernel: cheap at fp32 matrix rates);
+//   * input halo tile (6 rows x 66 cols x 16 ci) and the U slab of (nu, chunk) (24 KB) go global
+//     -> LDS with global_load_lds into double buffers (the next chunk lands while this one is
+//     multiplied); even / odd halo columns are de-interleaved so the 16 tiles of a lane group
+//     read consecutive 64-byte entries (2-way bank conflict on 8 reads per chunk: irrelevant);
+//     out-of-image pieces are sourced from a zero page;
+//   * V for the next chunk is formed (8 LDS reads, 32 adds) under the current chunk's last 24
+//     MFMAs; U fragments are read from LDS one xi ahead (conflict-free).
+#include "srgen_internal.h"
+
+#include <type_traits>
+
+namespace srgen {
+namespace c3w {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define MFMA16_F32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+constexpr int IN_ROWS = 6, IN_COLS = 66, HALF = IN_COLS / 2;       // 6 x (33 even + 33 odd)
+constexpr int CK = 16;                            // ci per chunk
+constexpr int ES = 16;                            // entry stride, floats
+constexpr int PIECES = IN_ROWS * 2 * HALF * 4;                      // 1,584 16-byte pieces per chunk
+constexpr int PIECE_REGS = (PIECES + 255) / 256;                    // 7 per thread (the 7th: 48 lanes of wave 0)
+constexpr int BUF_BYTES = (PIECES + 16) * 16;                       // 25,600 (the last wave piece overhangs by 16)
+constexpr int USLAB_BYTES = 4 * 4 * 96 * 16;                        // 24,576: U of one (nu, chunk): [xi][ci/4][co] float4
+constexpr int U_OFF = 2 * BUF_BYTES;                                // two U slabs behind the two halo buffers
+constexpr int BS_OFF = U_OFF + 2 * USLAB_BYTES;                     // bias[4][96], slope[4][96]
+constexpr int LDS_BYTES = BS_OFF + 2 * 4 * 96 * 4;                  // 103,424 (one workgroup per CU)
+constexpr int MAX_WGS = 256;                      // persistent grid: one workgroup per CU
+
+__device__ __forceinline__ int opaque(int v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+struct Item { int n, ty, tx, cb; };
+
+#ifdef SRGEN_C3W_STAMPS      // development only (tools/convbench_f32): per-item phase timestamps
+__device__ long long* g_wstamps = nullptr;
+#define C3W_STAMP(k)                                                                      \
+    do {                                                                                  \
+        if (g_wstamps && tid == 0) g_wstamps[(size_t)item * 16 + (k)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define C3W_STAMP(k) do { } while (0)
+#endif
+
+template <int HW, bool SHUFFLE, bool POOL, bool RES, bool ACT>
+__global__ __launch_bounds__(256, 1) void conv3x3_f32_wino_kernel(Conv3x3Args a, int nitems)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, kq = lane >> 4, c16 = lane & 15;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tr = w >> 1, tt = 16 * (w & 1) + c16;
+    constexpr int tiles_x = HW / 64, tiles_y = HW / 4, tiles_img = tiles_x * tiles_y;
+    constexpr int CB = SHUFFLE ? 4 : 1;
+
+    // persistent item walk: XCD x owns items [x*per, (x+1)*per) (see srgen_conv3x3_bf16.hip)
+    const int per_xcd = nitems >> 3;
+    const int wg_per_xcd = (int)gridDim.x >> 3;
+    const int xcd = blockIdx.x & 7;
+    const int item_end = (xcd + 1) * per_xcd;
+    int item = xcd * per_xcd + ((int)blockIdx.x >> 3);
+    auto decode = [&](int it) {
+        Item r;
+        r.cb = it % CB;
+        const int tile = it / CB;
+        r.tx = tile % tiles_x;
+        r.ty = (tile / tiles_x) % tiles_y;
+        r.n = tile / tiles_img;
+        return r;
+    };
+
+    float* const ldsBias = (float*)(lds + BS_OFF);
+    float* const ldsSlope = ldsBias + 4 * 96;
+    for (int i = tid; i < CB * 96; i += 256) {
+        ldsBias[i] = a.bias[i];
+        if (ACT) ldsSlope[i] = a.slope[i];
+    }
+
+    // ---- staging ---------------------------------------------------------------------------
+    // piece q (16 bytes) of a halo buffer: entry q/4 = (row r, column parity, idx), 4 ci q%4.  Per
+    // item every thread keeps the element offset of its 7 pieces inside the image (chunk 0), or -1
+    // for "source the zero page".
+    int aoff[PIECE_REGS];
+    auto plan_item = [&](const Item& it) {
+        const int x0 = it.tx * 64, y0 = it.ty * 4;
+        const int tv = opaque(tid);
+#pragma unroll
+        for (int k = 0; k < PIECE_REGS; ++k) {
+            const int q = tv + k * 256;
+            const int e = q >> 2, slot = q & 3;
+            const int r = e / (2 * HALF), rem = e - r * (2 * HALF);
+            const int par = rem / HALF, idx = rem - par * HALF;
+            const int gy = y0 - 1 + r, gx = x0 - 1 + 2 * idx + par;
+            const bool ok = q < PIECES && (unsigned)gy < (unsigned)HW && (unsigned)gx < (unsigned)HW;
+            aoff[k] = ok ? (gy * HW + gx) * kC + slot * 4 : -1;
+        }
+    };
+    // stage(item, nu, chunk, buf): halo chunk -> halo buffer buf, and the U slab of (cb, nu, chunk)
+    // -> U buffer buf.  Packed U: float4 units [cb][nu 4][chunk 6][xi 4][ci/4 4][co 96].
+    auto stage = [&](const Item& it, int nu, int chunk, int buf) {
+        const float* in = (const float*)a.in + (size_t)it.n * HW * HW * kC + chunk * CK;
+        char* dst = lds + buf * BUF_BYTES;
+#pragma unroll
+        for (int k = 0; k < PIECE_REGS; ++k) {
+            const float* src = aoff[k] >= 0 ? in + aoff[k] : (const float*)a.zeros;
+            if (k * 256 + w * 64 < PIECES) glds16(src, dst + (k * 256 + w * 64) * 16);
+        }
+        const char* usrc = (const char*)a.wpack + (size_t)((it.cb * 4 + nu) * 6 + chunk) * USLAB_BYTES + opaque(tid) * 16;
+        char* udst = lds + U_OFF + buf * USLAB_BYTES;
+#pragma unroll
+        for (int k = 0; k < USLAB_BYTES / 4096; ++k) glds16(usrc + k * 4096, udst + (k * 256 + w * 64) * 16);
+    };
+
+    // V[xi] (xi = 0..3) for column nu of a chunk, in two halves so the LDS latency sits under
+    // MFMAs: read_raw issues the 8 reads, combine does the adds.
+    //   e[a] = sum_b d[a][b] Bt[nu][b]:  nu0: d0 - d2   nu1: d1 + d2   nu2: d2 - d1   nu3: d1 - d3
+    //   V[xi] = sum_a Bt[xi][a] e[a]:    e0 - e2, e1 + e2, e2 - e1, e1 - e3
+    auto read_raw = [&](f32x4 (&R)[8], int nu, int buf) {
+        const int b0 = nu == 0 ? 0 : 1, b1 = nu == 3 ? 3 : 2;
+        const float* base = (const float*)(lds + buf * BUF_BYTES) + 4 * opaque(kq);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 2 * tr + r;
+            R[2 * r] = *(const f32x4*)(base + ((row * 2 + (b0 & 1)) * HALF + tt + (b0 >> 1)) * ES);
+            R[2 * r + 1] = *(const f32x4*)(base + ((row * 2 + (b1 & 1)) * HALF + tt + (b1 >> 1)) * ES);
+        }
+    };
+    auto combine = [&](f32x4 (&V)[4], const f32x4 (&R)[8], int nu) {
+        f32x4 e[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            e[r] = nu == 1 ? R[2 * r] + R[2 * r + 1] : nu == 2 ? R[2 * r + 1] - R[2 * r] : R[2 * r] - R[2 * r + 1];
+        V[0] = e[0] - e[2];
+        V[1] = e[1] + e[2];
+        V[2] = e[2] - e[1];
+        V[3] = e[1] - e[3];
+    };
+    struct UF { f32x4 u[6]; };
+    auto load_u = [&](UF& u, int buf, int xi) {
+        const f32x4* p = (const f32x4*)(lds + U_OFF + buf * USLAB_BYTES) + (xi * 4 + kq) * 96 + opaque(c16);
+#pragma unroll
+        for (int mt = 0; mt < 6; ++mt) u.u[mt] = p[16 * mt];
+    };
+
+    Item cur = decode(item);
+    plan_item(cur);
+    stage(cur, 0, 0, 0);
+    __syncthreads();
+
+    // pipeline registers: V of the current chunk, raw halo reads of the next, U fragments of the
+    // current and the next xi
+    f32x4 V[4], R[8];
+    UF ua, ub;
+    read_raw(R, 0, 0);
+    load_u(ua, 0, 0);
+    combine(V, R, 0);
+
+#pragma unroll 1
+    for (;;) {
+        const int nxt = item + wg_per_xcd;
+        const bool has_next = nxt < item_end;
+        const Item nx = decode(has_next ? nxt : item);
+        // y[i][j][mt]: output pixel (i, j) of the lane's tile, channels 16*mt + 4*kq .. +3
+        f32x4 y[2][2][6];
+#pragma unroll
+        for (int mt = 0; mt < 6; ++mt) {
+            const f32x4 b4 = *(const f32x4*)(ldsBias + cur.cb * 96 + 16 * mt + 4 * kq);
+            y[0][0][mt] = y[0][1][mt] = y[1][0][mt] = y[1][1][mt] = b4;
+        }
+
+        // ---- main loop: nu > chunk > xi, one flat software pipeline -----------------------------
+        // Invariant at the top of a chunk iteration: V holds this chunk's V, ua the U fragments of
+        // its xi = 0, and this chunk's LDS buffers have landed (barrier of the previous chunk).
+        auto run_nu = [&](auto NU) {
+            constexpr int nu = decltype(NU)::value;
+            constexpr int nu_next = (nu + 1) & 3;
+            f32x4 M[4][6];
+#pragma unroll
+            for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+                for (int mt = 0; mt < 6; ++mt) M[xi][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+            for (int chunk = 0; chunk < 6; ++chunk) {
+                const int buf = (nu * 6 + chunk) & 1;
+                const bool last_of_item = nu == 3 && chunk == 5;
+                const bool more = !last_of_item || has_next;
+                // next chunk (this nu's, the next nu's first, or the next item's first) -> other buffers
+                if (!last_of_item) stage(cur, chunk < 5 ? nu : nu_next, chunk < 5 ? chunk + 1 : 0, buf ^ 1);
+                else if (has_next) stage(nx, 0, 0, buf ^ 1);  // aoff was re-planned for nx before nu = 3
+#pragma unroll
+                for (int xi = 0; xi < 4; ++xi) {
+                    if (xi < 3) {
+                        if (xi & 1) load_u(ua, buf, xi + 1);
+                        else load_u(ub, buf, xi + 1);
+                    } else {
+                        // the next buffers (halo chunk + U slab) were issued three xi steps ago
+                        __syncthreads();
+                        if (more) {
+                            load_u(ua, buf ^ 1, 0);
+                            if (chunk < 5) read_raw(R, nu, buf ^ 1);
+                            else read_raw(R, nu_next, buf ^ 1);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    const UF& u = (xi & 1) ? ub : ua;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int mt = 0; mt < 6; ++mt) M[xi][mt] = MFMA16_F32(u.u[mt][e], V[xi][e], M[xi][mt]);
+                    if (xi == 3 && more) {
+                        if (chunk < 5) combine(V, R, nu);
+                        else combine(V, R, nu_next);
+                    }
+                }
+            }
+            C3W_STAMP(1 + 2 * nu);
+            // fold into the outputs: T_i = sum_xi At[i][xi] M[xi],  At = [[1,1,1,0],[0,1,-1,-1]];
+            // y[i][0] += T_i for nu = 0,1,2;  y[i][1] += T_i (nu 1), -= T_i (nu 2, 3).
+#pragma unroll
+            for (int mt = 0; mt < 6; ++mt) {
+                const f32x4 T0 = M[0][mt] + M[1][mt] + M[2][mt];
+                const f32x4 T1 = M[1][mt] - M[2][mt] - M[3][mt];
+                if (nu <= 2) { y[0][0][mt] += T0; y[1][0][mt] += T1; }
+                if (nu == 1) { y[0][1][mt] += T0; y[1][1][mt] += T1; }
+                if (nu >= 2) { y[0][1][mt] -= T0; y[1][1][mt] -= T1; }
+            }
+            C3W_STAMP(2 + 2 * nu);
+        };
+        C3W_STAMP(0);
+        run_nu(std::integral_constant<int, 0>{});
+        run_nu(std::integral_constant<int, 1>{});
+        run_nu(std::integral_constant<int, 2>{});
+        if (has_next) plan_item(nx);      // the last stage() of this item fetches the next item's chunk 0
+        run_nu(std::integral_constant<int, 3>{});
+
+        // ---- epilogue: PReLU -> (+ residual) -> 16-byte NHWC stores ------------------------------
+        const int oy = cur.ty * 4 + 2 * tr, ox = cur.tx * 64 + 2 * tt;
+        f32x4 psum[6];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float* out = (float*)a.out;
+                if (SHUFFLE)
+                    out += (((size_t)cur.n * 2 * HW + 2 * (oy + i) + (cur.cb >> 1)) * 2 * HW + 2 * (ox + j) + (cur.cb & 1)) * kC + 4 * kq;
+                else
+                    out += (((size_t)cur.n * HW + oy + i) * HW + ox + j) * kC + 4 * kq;
+                f32x4 rr[6];
+                if (RES) {
+                    const float* res = (const float*)a.res + (((size_t)cur.n * HW + oy + i) * HW + ox + j) * kC + 4 * kq;
+#pragma unroll
+                    for (int mt = 0; mt < 6; ++mt) rr[mt] = *(const f32x4*)(res + 16 * mt);
+                }
+#pragma unroll
+                for (int mt = 0; mt < 6; ++mt) {
+                    f32x4 v = y[i][j][mt];
+                    if (ACT) {
+                        const f32x4 s4 = *(const f32x4*)(ldsSlope + cur.cb * 96 + 16 * mt + 4 * kq);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.f ? v[e] : v[e] * s4[e];
+                    }
+                    if (RES) v += rr[mt];
+                    if (POOL) psum[mt] = (i == 0 && j == 0) ? v : psum[mt] + v;
+                    *(f32x4*)(out + 16 * mt) = v;
+                }
+            }
+        if (POOL) {
+            // per-item channel sums (ChannelAttention's pool), fixed order: xor butterfly over the 16
+            // tile lanes of each kq group, then the 4 waves through LDS.  P sits in halo buffer 1: the
+            // item's last chunk (sequence 23) used it and every wave is past that chunk's barrier and
+            // V reads; buffer 0 is being filled for the next item.
+            float* P = (float*)(lds + BUF_BYTES);
+            __syncthreads();
+#pragma unroll
+            for (int mt = 0; mt < 6; ++mt) {
+                f32x4 s = psum[mt];
+#pragma unroll
+                for (int b = 1; b < 16; b <<= 1)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) s[e] += __shfl_xor(s[e], b);
+                if (c16 == 0) *(f32x4*)(P + w * kC + 16 * mt + 4 * kq) = s;
+            }
+            __syncthreads();
+            if (tid < kC) {
+                const float s = (P[tid] + P[kC + tid]) + (P[2 * kC + tid] + P[3 * kC + tid]);
+                a.pool_partial[((size_t)cur.n * tiles_img + cur.ty * tiles_x + cur.tx) * kC + tid] = s;
+            }
+            __syncthreads();
+        }
+        C3W_STAMP(9);
+        if (!has_next) break;
+        item = nxt;
+        cur = nx;
+    }
+}
+
+template <int HW, bool SHUFFLE, bool POOL, bool RES, bool ACT>
+hipError_t launch_one(const Conv3x3Args& a, hipStream_t s)
+{
+    static bool attr_set[64] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+        e = hipFuncSetAttribute((const void*)conv3x3_f32_wino_kernel<HW, SHUFFLE, POOL, RES, ACT>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    }
+    const int nitems = a.N * (HW / 4) * (HW / 64) * (SHUFFLE ? 4 : 1);     // multiple of 16
+    const int grid = nitems < MAX_WGS ? nitems & ~7 : MAX_WGS;
+    hipLaunchKernelGGL((conv3x3_f32_wino_kernel<HW, SHUFFLE, POOL, RES, ACT>), dim3((unsigned)grid), dim3(256), LDS_BYTES,
+                       s, a, nitems);
+    return hipGetLastError();
+}
+
+}  // namespace c3w
+
+hipError_t launch_conv3x3_f32_wino(const Conv3x3Args& a, hipStream_t s)
+{
+    using namespace c3w;
+    if (a.H != a.W || a.N <= 0 || !a.zeros) return hipErrorInvalidValue;
+    const bool res = a.res != nullptr, pool = a.pool_partial != nullptr, act = a.slope != nullptr;
+    // the generator only ever pairs (PReLU, no residual) or (residual, no PReLU)
+    if (a.H == kLR && !a.shuffle && a.cout_blocks == 1) {
+        if (!pool && !res && act) return launch_one<kLR, false, false, false, true>(a, s);
+        if (!pool && res && !act) return launch_one<kLR, false, false, true, false>(a, s);
+        if (pool && res && !act) return launch_one<kLR, false, true, true, false>(a, s);
+    }
+    if (a.H == kLR && a.shuffle && a.cout_blocks == 4 && !pool && !res && act) return launch_one<kLR, true, false, false, true>(a, s);
+    if (a.H == kHR && !a.shuffle && a.cout_blocks == 1 && !pool && !res && act) return launch_one<kHR, false, false, false, true>(a, s);
+    return hipErrorInvalidValue;
+}
+
+}  // namespace srgen

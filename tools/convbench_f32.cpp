@@ -3,8 +3,9 @@
 // each other and against a CPU spot check.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -o tools/bin/convbench tools/convbench.cpp
 //   tools/bin/convbench [N=256] [rounds=5] [launches=20] [mode: 0 trunk, 1 trunk+res, 2 shuffle, 3 hr, 4 pool]
-#include "conv3x3_f32_v1.hip"
+#define SRGEN_C3W_STAMPS 1
 #include "../superresolution_amd/csrc/srgen_conv3x3_f32.hip"
+#include "../superresolution_amd/csrc/srgen_conv3x3_f32_wino.hip"
 
 #include <algorithm>
 #include <cmath>
@@ -47,6 +48,7 @@ int main(int argc, char** argv)
     const int rounds = argc > 2 ? atoi(argv[2]) : 5;
     const int launches = argc > 3 ? atoi(argv[3]) : 20;
     const int mode = argc > 4 ? atoi(argv[4]) : 1;
+    const bool use_wino = argc > 5 ? atoi(argv[5]) != 0 : true;      // variant "v2" = Winograd kernel
     const int H = mode == 3 ? 128 : 64;
     const int cb = mode == 2 ? 4 : 1;
     const size_t in_elems = (size_t)N * H * H * 96;
@@ -75,6 +77,30 @@ int main(int argc, char** argv)
     CK(hipMemcpy(d_in, h_in.data(), in_elems * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_res, h_res.data(), in_elems * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_w, h_w.data(), w_elems * 4, hipMemcpyHostToDevice));
+    // Winograd weights U = G g Gt, float4 units [cb][nu 4][chunk 6][xi 4][ci/4 4][co 96]
+    std::vector<float> h_u((size_t)cb * 16 * 96 * 96);
+    {
+        const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+        for (int b = 0; b < cb; ++b)
+            for (int co = 0; co < 96; ++co)
+                for (int ci = 0; ci < 96; ++ci) {
+                    double g[3][3];
+                    for (int tap = 0; tap < 9; ++tap)
+                        g[tap / 3][tap % 3] = h_w[((((size_t)b * 9 + tap) * 24 + ci / 4) * 96 + co) * 4 + (ci & 3)];
+                    for (int xi = 0; xi < 4; ++xi)
+                        for (int nu = 0; nu < 4; ++nu) {
+                            double u = 0;
+                            for (int a = 0; a < 3; ++a)
+                                for (int c = 0; c < 3; ++c) u += G[xi][a] * g[a][c] * G[nu][c];
+                            h_u[((((((size_t)b * 4 + nu) * 6 + ci / 16) * 4 + xi) * 4 + (ci / 4) % 4) * 96 + co) * 4 + (ci & 3)] = (float)u;
+                        }
+                }
+    }
+    float *d_u, *d_zeros;
+    CK(hipMalloc(&d_u, h_u.size() * 4));
+    CK(hipMemcpy(d_u, h_u.data(), h_u.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMalloc(&d_zeros, 256));
+    CK(hipMemset(d_zeros, 0, 256));
     CK(hipMemcpy(d_bias, h_bias.data(), 96 * cb * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_slope, h_slope.data(), 96 * cb * 4, hipMemcpyHostToDevice));
 
@@ -85,12 +111,14 @@ int main(int argc, char** argv)
         a.res = (mode == 1 || mode == 4) ? d_res : nullptr;
         a.pool_partial = mode == 4 ? d_pool[which] : nullptr;
         a.N = N; a.H = H; a.W = H; a.cout_blocks = cb; a.shuffle = mode == 2;
+        a.zeros = d_zeros;
+        if (which == 1 && use_wino) a.wpack = d_u;
         return a;
     };
     hipStream_t s;
     CK(hipStreamCreate(&s));
     auto run = [&](int which) {
-        return which == 0 ? v1f::launch_conv3x3_f32(args(0), s) : launch_conv3x3_f32(args(1), s);
+        return which == 0 ? launch_conv3x3_f32(args(0), s) : (use_wino ? launch_conv3x3_f32_wino(args(1), s) : launch_conv3x3_f32(args(1), s));
     };
     for (int i = 0; i < 2; ++i) {
         CK(hipMemsetAsync(d_out[i], 0xff, out_elems * 4, s));
@@ -171,6 +199,26 @@ int main(int argc, char** argv)
         const double m = med[which][med[which].size() / 2], b = med[which][0];
         printf("v%d: median %.4f ms (%.1f TFLOP/s)  min %.4f ms (%.1f TFLOP/s)\n", which + 1, m,
                flop / m * 1e-9, b, flop / b * 1e-9);
+    }
+    if (use_wino) {   // phase stamps of the Winograd kernel (one launch)
+        const size_t nit = (size_t)N * (H / 4) * (H / 64) * cb;
+        long long* d_st;
+        CK(hipMalloc(&d_st, nit * 16 * 8));
+        CK(hipMemset(d_st, 0, nit * 16 * 8));
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(c3w::g_wstamps), &d_st, sizeof(d_st)));
+        CK(run(1));
+        CK(hipStreamSynchronize(s));
+        std::vector<long long> st(nit * 16);
+        CK(hipMemcpy(st.data(), d_st, nit * 16 * 8, hipMemcpyDeviceToHost));
+        const char* names[9] = {"nu0 loop", "nu0 fold", "nu1 loop", "nu1 fold", "nu2 loop", "nu2 fold", "nu3 loop", "nu3 fold", "epilogue"};
+        for (int k = 0; k < 9; ++k) {
+            std::vector<long long> d;
+            for (size_t i = 0; i < nit; ++i) d.push_back(st[i * 16 + k + 1] - st[i * 16 + k]);
+            std::sort(d.begin(), d.end());
+            printf("  %-10s median %7lld  p10 %7lld  p90 %7lld ticks\n", names[k], d[d.size() / 2], d[d.size() / 10], d[d.size() * 9 / 10]);
+        }
+        void* nul = nullptr;
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(c3w::g_wstamps), &nul, sizeof(nul)));
     }
     return 0;
 }
