@@ -44,12 +44,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define MFMA16_F32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
-constexpr int IN_ROWS = 6, IN_COLS = 66, HALF = IN_COLS / 2;       // 6 x (33 even + 33 odd)
+constexpr int IN_ROWS = 6;                        // halo rows of an item (4 output rows + 2)
 constexpr int CK = 16;                            // ci per chunk
-constexpr int ES = 16;                            // entry stride, floats
-constexpr int PIECES = IN_ROWS * 2 * HALF * 4;                      // 1,584 16-byte pieces per chunk
-constexpr int PIECE_REGS = (PIECES + 255) / 256;                    // 7 per thread (the 7th: 48 lanes of wave 0)
-constexpr int BUF_BYTES = (PIECES + 16) * 16;                       // 25,600 (the last wave piece overhangs by 16)
+constexpr int ENTRY = 64;                         // bytes per halo entry (one pixel, 16 ci)
+// Halo buffer: row r at r*ROWB holds the item's 64 interior columns, de-interleaved: entry
+// (par*32 + idx) = column 2*idx + par -- exactly the 256 16-byte pieces one glds round of the
+// workgroup writes, from ONE global row segment (validity depends on the row only: wave-uniform).
+// The two edge columns (-1 and 64) of the 6 rows sit behind the rows: entry EDGE_OFF + (r*2 + LR).
+constexpr int ROWB = 64 * ENTRY;                                    // 4,096
+constexpr int EDGE_OFF = IN_ROWS * ROWB;                            // 24,576
+constexpr int BUF_BYTES = EDGE_OFF + 1024;                          // 25,600 (edge piece = one wave piece, 768 B used)
 constexpr int USLAB_BYTES = 4 * 4 * 96 * 16;                        // 24,576: U of one (nu, chunk): [xi][ci/4][co] float4
 constexpr int U_OFF = 2 * BUF_BYTES;                                // two U slabs behind the two halo buffers
 constexpr int BS_OFF = U_OFF + 2 * USLAB_BYTES;                     // bias[4][96], slope[4][96]
@@ -114,52 +118,64 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f32_wino_kernel(Conv3x3Args a,
     }
 
     // ---- staging ---------------------------------------------------------------------------
-    // piece q (16 bytes) of a halo buffer: entry q/4 = (row r, column parity, idx), 4 ci q%4.  Per
-    // item every thread keeps the element offset of its 7 pieces inside the image (chunk 0), or -1
-    // for "source the zero page".
-    int aoff[PIECE_REGS];
-    auto plan_item = [&](const Item& it) {
-        const int x0 = it.tx * 64, y0 = it.ty * 4;
-        const int tv = opaque(tid);
-#pragma unroll
-        for (int k = 0; k < PIECE_REGS; ++k) {
-            const int q = tv + k * 256;
-            const int e = q >> 2, slot = q & 3;
-            const int r = e / (2 * HALF), rem = e - r * (2 * HALF);
-            const int par = rem / HALF, idx = rem - par * HALF;
-            const int gy = y0 - 1 + r, gx = x0 - 1 + 2 * idx + par;
-            const bool ok = q < PIECES && (unsigned)gy < (unsigned)HW && (unsigned)gx < (unsigned)HW;
-            aoff[k] = ok ? (gy * HW + gx) * kC + slot * 4 : -1;
-        }
-    };
     // stage(item, nu, chunk, buf): halo chunk -> halo buffer buf, and the U slab of (cb, nu, chunk)
-    // -> U buffer buf.  Packed U: float4 units [cb][nu 4][chunk 6][xi 4][ci/4 4][co 96].
-    auto stage = [&](const Item& it, int nu, int chunk, int buf) {
-        const float* in = (const float*)a.in + (size_t)it.n * HW * HW * kC + chunk * CK;
+    // -> U buffer buf.  Packed U: float4 units [cb][nu 4][chunk 6][xi 4][ci/4 4][co 96].  A thread's
+    // piece of halo row k is its own fixed 16 bytes of that row's 64-pixel segment (byte offset
+    // row_off); rows outside the image come from the zero page (kWinoZeroBytes) at the same offset.
+    constexpr bool EDGES = tiles_x > 1;            // with one tile per image row both edge columns are padding
+    if (!EDGES && tid < 128) {                     // ... zeroed once, never staged
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        *(f32x4*)(lds + (tid >> 6) * BUF_BYTES + EDGE_OFF + (tid & 63) * 16) = z;
+    }
+    const int row_off = ((2 * ((tid >> 2) & 31) + ((tid >> 7) & 1)) * kC + (tid & 3) * 4) * 4;
+    // part 0 / 1 / 2: thirds of the pieces, issued before the MFMA blocks of xi = 0 / 1 / 2; -1: all
+    auto stage = [&](const Item& it, int nu, int chunk, int buf, int part) {
+        const char* in = (const char*)((const float*)a.in + ((size_t)it.n * HW * HW + it.tx * 64) * kC + chunk * CK);
         char* dst = lds + buf * BUF_BYTES;
+        const int y0 = it.ty * 4 - 1;
 #pragma unroll
-        for (int k = 0; k < PIECE_REGS; ++k) {
-            const float* src = aoff[k] >= 0 ? in + aoff[k] : (const float*)a.zeros;
-            if (k * 256 + w * 64 < PIECES) glds16(src, dst + (k * 256 + w * 64) * 16);
+        for (int k = 0; k < IN_ROWS; ++k) {
+            if (part >= 0 && part != k / 4) continue;
+            const int gy = y0 + k;
+            const char* rowp = (unsigned)gy < (unsigned)HW ? in + (size_t)gy * (HW * kC * 4) : (const char*)a.zeros;
+            glds16(rowp + opaque(row_off), dst + k * ROWB + w * 1024);
+        }
+        if (EDGES && w == 0 && (part < 0 || part == 1)) {       // edge columns: lane l -> row l/8, side (l/4)&1, 4 ci l&3
+            const int l = opaque(lane);
+            const int gy = y0 + (l >> 3), dx = ((l >> 2) & 1) ? 64 : -1, gx = it.tx * 64 + dx;
+            const bool ok = l < 48 && (unsigned)gy < (unsigned)HW && (unsigned)gx < (unsigned)HW;
+            const char* src = ok ? in + ((ptrdiff_t)gy * HW + dx) * (kC * 4) + (l & 3) * 16 : (const char*)a.zeros;
+            glds16(src, dst + EDGE_OFF);
         }
         const char* usrc = (const char*)a.wpack + (size_t)((it.cb * 4 + nu) * 6 + chunk) * USLAB_BYTES + opaque(tid) * 16;
         char* udst = lds + U_OFF + buf * USLAB_BYTES;
 #pragma unroll
-        for (int k = 0; k < USLAB_BYTES / 4096; ++k) glds16(usrc + k * 4096, udst + (k * 256 + w * 64) * 16);
+        for (int k = 0; k < USLAB_BYTES / 4096; ++k)
+            if (part < 0 || part == (k < 2 ? 1 : 2)) glds16(usrc + k * 4096, udst + (k * 256 + w * 64) * 16);
     };
 
     // V[xi] (xi = 0..3) for column nu of a chunk, in two halves so the LDS latency sits under
     // MFMAs: read_raw issues the 8 reads, combine does the adds.
     //   e[a] = sum_b d[a][b] Bt[nu][b]:  nu0: d0 - d2   nu1: d1 + d2   nu2: d2 - d1   nu3: d1 - d3
     //   V[xi] = sum_a Bt[xi][a] e[a]:    e0 - e2, e1 + e2, e2 - e1, e1 - e3
+    // Input column b (0..3) of tile tt is image column 2*tt - 1 + b: b = 1, 2 -> (par 0 / 1, idx tt);
+    // b = 0 -> (par 1, idx tt - 1) or the left edge entry; b = 3 -> (par 0, idx tt + 1) or the right
+    // edge entry.  Per lane: byte offset of halo row 2*tr and the row stride, for each b.
+    int rb[4], rs[4];
+    rb[1] = (2 * tr) * ROWB + tt * ENTRY + 16 * kq;
+    rb[2] = (2 * tr) * ROWB + (32 + tt) * ENTRY + 16 * kq;
+    rb[0] = tt > 0 ? (2 * tr) * ROWB + (32 + tt - 1) * ENTRY + 16 * kq : EDGE_OFF + (2 * tr) * 2 * ENTRY + 16 * kq;
+    rb[3] = tt < 31 ? (2 * tr) * ROWB + (tt + 1) * ENTRY + 16 * kq : EDGE_OFF + ((2 * tr) * 2 + 1) * ENTRY + 16 * kq;
+    rs[1] = rs[2] = ROWB;
+    rs[0] = tt > 0 ? ROWB : 2 * ENTRY;
+    rs[3] = tt < 31 ? ROWB : 2 * ENTRY;
     auto read_raw = [&](f32x4 (&R)[8], int nu, int buf) {
         const int b0 = nu == 0 ? 0 : 1, b1 = nu == 3 ? 3 : 2;
-        const float* base = (const float*)(lds + buf * BUF_BYTES) + 4 * opaque(kq);
+        const char* base = lds + buf * BUF_BYTES;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int row = 2 * tr + r;
-            R[2 * r] = *(const f32x4*)(base + ((row * 2 + (b0 & 1)) * HALF + tt + (b0 >> 1)) * ES);
-            R[2 * r + 1] = *(const f32x4*)(base + ((row * 2 + (b1 & 1)) * HALF + tt + (b1 >> 1)) * ES);
+            R[2 * r] = *(const f32x4*)(base + opaque(rb[b0]) + r * (b0 == 1 ? ROWB : rs[b0]));
+            R[2 * r + 1] = *(const f32x4*)(base + opaque(rb[b1]) + r * (b1 == 2 ? ROWB : rs[b1]));
         }
     };
     auto combine = [&](f32x4 (&V)[4], const f32x4 (&R)[8], int nu) {
@@ -180,8 +196,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f32_wino_kernel(Conv3x3Args a,
     };
 
     Item cur = decode(item);
-    plan_item(cur);
-    stage(cur, 0, 0, 0);
+    stage(cur, 0, 0, 0, -1);
     __syncthreads();
 
     // pipeline registers: V of the current chunk, raw halo reads of the next, U fragments of the
@@ -222,11 +237,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f32_wino_kernel(Conv3x3Args a,
                 const bool last_of_item = nu == 3 && chunk == 5;
                 const bool more = !last_of_item || has_next;
                 // next chunk (this nu's, the next nu's first, or the next item's first) -> other buffers
-                if (!last_of_item) stage(cur, chunk < 5 ? nu : nu_next, chunk < 5 ? chunk + 1 : 0, buf ^ 1);
-                else if (has_next) stage(nx, 0, 0, buf ^ 1);  // aoff was re-planned for nx before nu = 3
 #pragma unroll
                 for (int xi = 0; xi < 4; ++xi) {
                     if (xi < 3) {
+                        // next chunk (this nu's, the next nu's first, or the next item's first) -> other buffers
+                        if (!last_of_item) stage(cur, chunk < 5 ? nu : nu_next, chunk < 5 ? chunk + 1 : 0, buf ^ 1, xi);
+                        else if (has_next) stage(nx, 0, 0, buf ^ 1, xi);
                         if (xi & 1) load_u(ua, buf, xi + 1);
                         else load_u(ub, buf, xi + 1);
                     } else {
@@ -267,7 +283,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f32_wino_kernel(Conv3x3Args a,
         run_nu(std::integral_constant<int, 0>{});
         run_nu(std::integral_constant<int, 1>{});
         run_nu(std::integral_constant<int, 2>{});
-        if (has_next) plan_item(nx);      // the last stage() of this item fetches the next item's chunk 0
         run_nu(std::integral_constant<int, 3>{});
 
         // ---- epilogue: PReLU -> (+ residual) -> 16-byte NHWC stores ------------------------------
@@ -356,7 +371,7 @@ hipError_t launch_one(const Conv3x3Args& a, hipStream_t s)
 hipError_t launch_conv3x3_f32_wino(const Conv3x3Args& a, hipStream_t s)
 {
     using namespace c3w;
-    if (a.H != a.W || a.N <= 0 || !a.zeros) return hipErrorInvalidValue;
+    if (a.H != a.W || a.N <= 0 || !a.zeros) return hipErrorInvalidValue;       // zeros: kWinoZeroBytes
     const bool res = a.res != nullptr, pool = a.pool_partial != nullptr, act = a.slope != nullptr;
     // the generator only ever pairs (PReLU, no residual) or (residual, no PReLU)
     if (a.H == kLR && !a.shuffle && a.cout_blocks == 1) {

@@ -26,8 +26,8 @@ struct Conv3x3Args {
     int N, H, W;
     int cout_blocks;       // 1, or 4 for the upsample conv
     int shuffle;           // 1: PixelShuffle(2) store (cout block b -> sub-pixel (b>>1, b&1))
-    const void* zeros = nullptr;   // >= 16 zero bytes in device memory (Winograd kernel: source of
-                                   // out-of-image halo pieces for global_load_lds), else unused
+    const void* zeros = nullptr;   // kWinoZeroBytes zero bytes in device memory (Winograd kernel: source
+                                   // of out-of-image halo rows for global_load_lds), else unused
 };
 
 // ---- 9x9 stem, NCHW 3ch in -> NHWC 96 out, bias + PReLU ---------------------------------
@@ -70,6 +70,7 @@ hipError_t launch_conv3x3_f32(const Conv3x3Args& a, hipStream_t s);
 // as float4 units [cb][nu 4][ci chunk 6][xi 4][ci/4 4][co 96]; needs Conv3x3Args::zeros; same
 // pool_partial tiling as the direct kernel
 hipError_t launch_conv3x3_f32_wino(const Conv3x3Args& a, hipStream_t s);
+constexpr size_t kWinoZeroBytes = 64 * 96 * 4;        // one 64-pixel row of 96 channels
 hipError_t launch_chan_attn_f32(const ChanAttnArgs& a, hipStream_t s);
 hipError_t launch_head_f32(const HeadArgs& a, hipStream_t s);
 // bf16 kernels (srgen_kernels_bf16.hip)

@@ -99,8 +99,8 @@ int main(int argc, char** argv)
     float *d_u, *d_zeros;
     CK(hipMalloc(&d_u, h_u.size() * 4));
     CK(hipMemcpy(d_u, h_u.data(), h_u.size() * 4, hipMemcpyHostToDevice));
-    CK(hipMalloc(&d_zeros, 256));
-    CK(hipMemset(d_zeros, 0, 256));
+    CK(hipMalloc(&d_zeros, kWinoZeroBytes));
+    CK(hipMemset(d_zeros, 0, kWinoZeroBytes));
     CK(hipMemcpy(d_bias, h_bias.data(), 96 * cb * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_slope, h_slope.data(), 96 * cb * 4, hipMemcpyHostToDevice));
 
