@@ -11,8 +11,9 @@ data-path collective); the only collective is the metric all-reduce of evaluate(
 timed forward.  Rank 0 prints ONE JSON line.
 
 Extra objects on that line:
-  roofline      dominant kernel = conv3x3_<dtype>_kernel<64, ...> (the 33 trunk 3x3 convs, 75 % of
-                the FLOPs).  achieved = algorithmic FLOPs per launch (2*4096*96*864 per image x
+  roofline      dominant kernel = the 33 trunk 3x3 convs, 75 % of the FLOPs: conv3x3_bf16_kernel<64,...>
+                or, for fp32, the Winograd kernel conv3x3_f32_wino_kernel<64,...> (SRGEN_F32_CONV3X3=direct
+                selects conv3x3_f32_kernel).  achieved = algorithmic FLOPs per launch (2*4096*96*864 per image x
                 batch) / average launch duration measured live with HIP events on the launch
                 stream (srgen_forward_profile); peak = 157.3 TFLOP/s fp32 matrix / 2500 TFLOP/s
                 bf16 dense (MI355X_MICROARCH.md); traffic = HBM bytes per launch from the committed
@@ -134,11 +135,21 @@ def main():
                 traffic = json.load(open(tpath)).get("conv3x3_trunk_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        roof = {"bound": "mfma", "kernel": f"conv3x3_{args.dtype}_kernel<64,false,*,*> (33 trunk launches)",
+        wino = args.dtype == "f32" and os.environ.get("SRGEN_F32_CONV3X3") != "direct"
+        kname = "conv3x3_f32_wino_kernel<64,false,*,*,*>" if wino else f"conv3x3_{args.dtype}_kernel<64,false,*,*>"
+        roof = {"bound": "mfma", "kernel": f"{kname} (33 trunk launches)",
                 "achieved": round(achieved, 2), "peak": PEAK[args.dtype], "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK[args.dtype], 4), "traffic": traffic,
                 "ms_per_launch": round(ms_launch, 4),
                 "flop_per_launch": TRUNK_CONV_FLOP_PER_IMAGE * args.batch}
+        if wino:
+            # Winograd F(2x2,3x3) multiplies 16 instead of 36 times per (ci, co, 2x2 outputs): the
+            # matrix pipe executes 4/9 of the algorithmic FLOPs, so `frac` (algorithmic / peak) can
+            # exceed 1; what the MFMA units are actually kept busy with is mfma_executed.
+            roof["mfma_executed"] = round(achieved * 16 / 36, 2)
+            roof["mfma_executed_frac"] = round(achieved * 16 / 36 / PEAK[args.dtype], 4)
+            roof["note"] = ("Winograd F(2x2,3x3): achieved/frac count the conv's algorithmic FLOPs (SURVEY 8d); "
+                            "the kernel executes 4/9 of them on the matrix pipe (mfma_executed)")
 
     # ---- HBM-bound kernels of the path: achieved GB/s against the 8 TB/s HBM3E peak ------------
     hbm = {}

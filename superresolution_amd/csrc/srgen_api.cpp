@@ -14,6 +14,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <map>
 #include <string>
 #include <vector>
@@ -53,7 +54,7 @@ inline uint16_t f32_to_bf16(float f)
 }
 
 struct ConvDev {           // offsets (bytes) into the device weight blob
-    size_t w_f32 = 0, w_bf16 = 0, bias = 0, slope = 0;
+    size_t w_f32 = 0, w_wino = 0, w_bf16 = 0, bias = 0, slope = 0;
     bool has_slope = false;
     int cout_blocks = 1;
 };
@@ -71,6 +72,8 @@ struct srgen_handle {
     ConvDev stem, mid, up, out0, head;
     std::vector<ConvDev> conv1, conv2;   // per residual block
     CaDev ca[2];
+    size_t zeros = 0;              // kWinoZeroBytes of zeros in the blob (Winograd halo padding rows)
+    bool f32_wino = true;          // fp32 3x3 convs: Winograd F(2x2,3x3) kernel (default) or the direct one
 };
 
 namespace {
@@ -189,6 +192,31 @@ std::vector<float> pack3x3_f32(const Folded& f, int cb, const std::vector<int>& 
     return p;
 }
 
+// fp32 Winograd image: U = G g Gt (F(2x2,3x3); G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]), formed in
+// fp64 from the folded weights and rounded once; float4 units [cb][nu 4][ci chunk 6][xi 4][ci/4 4]
+// [co 96] (4 consecutive ci per unit): one (cb, nu, chunk) slab is what srgen_conv3x3_f32_wino.hip
+// stages per step.
+std::vector<float> pack3x3_wino_f32(const Folded& f, int cb, const std::vector<int>& perm)
+{
+    static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    std::vector<float> p((size_t)cb * 16 * 96 * 96);
+    for (int b = 0; b < cb; ++b)
+        for (int co = 0; co < 96; ++co) {
+            const int oc = perm[b * 96 + co];
+            for (int ci = 0; ci < 96; ++ci) {
+                const float* g = &f.w[((size_t)oc * 96 + ci) * 9];
+                for (int xi = 0; xi < 4; ++xi)
+                    for (int nu = 0; nu < 4; ++nu) {
+                        double u = 0;
+                        for (int r = 0; r < 3; ++r)
+                            for (int c = 0; c < 3; ++c) u += G[xi][r] * (double)g[r * 3 + c] * G[nu][c];
+                        p[((((((size_t)b * 4 + nu) * 6 + ci / 16) * 4 + xi) * 4 + (ci / 4) % 4) * 96 + co) * 4 + (ci & 3)] = (float)u;
+                    }
+            }
+        }
+    return p;
+}
+
 // bf16 image: 8-element units [cb][tap][ci/8][co 96] (8 consecutive ci per unit = one
 // 32x32x16 B fragment element group).
 std::vector<uint16_t> pack3x3_bf16(const Folded& f, int cb, const std::vector<int>& perm)
@@ -284,6 +312,7 @@ ConvDev emit_conv3x3(Blob& blob, const Folded& f, int cb, const std::vector<int>
     ConvDev d;
     d.cout_blocks = cb;
     d.w_f32 = blob.put_f32(pack3x3_f32(f, cb, perm));
+    d.w_wino = blob.put_f32(pack3x3_wino_f32(f, cb, perm));
     d.w_bf16 = blob.put_u16(pack3x3_bf16(f, cb, perm));
     std::vector<float> bias((size_t)cb * 96), slope((size_t)cb * 96, 1.f);
     for (int i = 0; i < cb * 96; ++i) {
@@ -355,6 +384,8 @@ int srgen_create(const srgen_config* cfg, srgen_handle** out)
     if (!h) return fail(SRGEN_E_INVALID, "out of host memory");
     h->cfg = *cfg;
     h->device = dev;
+    // development / test switch: SRGEN_F32_CONV3X3=direct selects the direct fp32 3x3 kernel
+    if (const char* e = getenv("SRGEN_F32_CONV3X3")) h->f32_wino = strcmp(e, "direct") != 0;
     *out = h;
     return SRGEN_OK;
 }
@@ -400,6 +431,7 @@ int srgen_commit_weights(srgen_handle* h, void* stream)
                            nmiss > 4 ? ", ..." : "");
 
     Blob blob;
+    h->zeros = blob.reserve(kWinoZeroBytes);
     const std::vector<int> id96 = identity_perm(96);
     {   // stem: conv 9x9 + scalar PReLU                                   Generator.py:49-52
         Folded f = fold(h, "input.0", "", 1.0, 96, 3, 9);
@@ -515,7 +547,9 @@ static int run_forward(srgen_handle* h, const void* x, void* y, void* workspace,
                     int shuffle) -> hipError_t {
         Conv3x3Args a;
         a.in = in; a.out = out;
-        a.wpack = B + (bf ? d.w_bf16 : d.w_f32);
+        const bool wino = !bf && h->f32_wino;
+        a.wpack = B + (bf ? d.w_bf16 : wino ? d.w_wino : d.w_f32);
+        a.zeros = B + h->zeros;
         a.bias = F(d.bias);
         a.slope = d.has_slope ? F(d.slope) : nullptr;
         a.res = res; a.pool_partial = pool;
@@ -523,7 +557,7 @@ static int run_forward(srgen_handle* h, const void* x, void* y, void* workspace,
         a.cout_blocks = d.cout_blocks; a.shuffle = shuffle;
         hipError_t e = tick(shuffle ? SRGEN_K_CONV3X3_UP : (H == kLR ? SRGEN_K_CONV3X3_TRUNK : SRGEN_K_CONV3X3_HR));
         if (e != hipSuccess) return e;
-        e = bf ? launch_conv3x3_bf16(a, s) : launch_conv3x3_f32(a, s);
+        e = bf ? launch_conv3x3_bf16(a, s) : wino ? launch_conv3x3_f32_wino(a, s) : launch_conv3x3_f32(a, s);
         if (e != hipSuccess) return e;
         return tock();
     };

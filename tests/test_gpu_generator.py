@@ -60,6 +60,26 @@ def test_fp32_vs_cpu_oracle_other_seed(synth_sd_np):
     assert max_rel(y, ref) <= FP32_TOL
 
 
+def test_fp32_direct_conv_kernel_matches_golden_and_winograd(gen, golden, golden_inputs, monkeypatch):
+    """The fp32 3x3 convs run the Winograd F(2x2,3x3) kernel by default; the direct kernel
+    (SRGEN_F32_CONV3X3=direct at handle creation) must meet the same bar, and the two must agree
+    far inside it, on a batch whose work items straddle rows, images and workgroup counts."""
+    from superresolution_amd import Generator, weights as W
+    monkeypatch.setenv("SRGEN_F32_CONV3X3", "direct")
+    g = Generator()
+    g.load_state_dict(W.synthetic_state_dict(0))
+    g = g.cuda().eval()
+    x2 = torch.from_numpy(golden_inputs).cuda()
+    yd = g(x2)
+    assert max_rel(yd.cpu().numpy(), golden["y_dense_sparse"]) <= FP32_TOL
+    x = torch.from_numpy(W.synthetic_lr_batch(19, seed=11)).cuda()
+    yw, tw = gen.forward_taps(x)
+    yd, td = g.forward_taps(x)
+    assert max_rel(yw.cpu().numpy(), yd.cpu().numpy()) <= 2e-5
+    for nm in ("block0", "ca8", "skip", "upsample", "output1"):
+        assert max_rel(tw[nm].cpu().numpy(), td[nm].cpu().numpy()) <= 2e-5, nm
+
+
 # ---- bf16 (BASELINE.json configs[2]) --------------------------------------------------------
 def _psnr(a, b):
     mse = float(np.mean((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2))

@@ -33,7 +33,7 @@ def pmc_means(d):
 
 def is_trunk(name, dt):
     # the 33 trunk launches: conv3x3_<dt>_kernel<64, false(shuffle), pool?, res?>
-    return f"conv3x3_{dt}_kernel<64, false" in name
+    return f"conv3x3_{dt}_kernel<64, false" in name or f"conv3x3_{dt}_wino_kernel<64, false" in name
 
 
 def main():
