@@ -74,6 +74,18 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base)
 
 struct Item { int n, ty, tx, cb; };
 
+// The 2x2 output accumulators are touched only by the four folds and the epilogue of an item, but
+// are live across all of its 2,304 MFMAs; left to the register allocator they compete with the
+// pipeline registers for the 256 architectural VGPRs and spill.  Pin them to the accumulator half
+// of the register file (vector ALU instructions cannot address it, hence the explicit moves).
+__device__ __forceinline__ float acc_get(float a)
+{
+    float v;
+    asm("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a));
+    return v;
+}
+__device__ __forceinline__ void acc_set(float& a, float v) { asm("v_accvgpr_write_b32 %0, %1" : "=a"(a) : "v"(v)); }
+
 #ifdef SRGEN_C3W_STAMPS      // development only (tools/convbench_f32): per-item phase timestamps
 __device__ long long* g_wstamps = nullptr;
 #define C3W_STAMP(k)                                                                      \
@@ -213,11 +225,17 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f32_wino_kernel(Conv3x3Args a,
         const bool has_next = nxt < item_end;
         const Item nx = decode(has_next ? nxt : item);
         // y[i][j][mt]: output pixel (i, j) of the lane's tile, channels 16*mt + 4*kq .. +3
-        f32x4 y[2][2][6];
+        float y[2][2][6][4];             // (accumulator registers: acc_get / acc_set)
 #pragma unroll
         for (int mt = 0; mt < 6; ++mt) {
             const f32x4 b4 = *(const f32x4*)(ldsBias + cur.cb * 96 + 16 * mt + 4 * kq);
-            y[0][0][mt] = y[0][1][mt] = y[1][0][mt] = y[1][1][mt] = b4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                acc_set(y[0][0][mt][r], b4[r]);
+                acc_set(y[0][1][mt][r], b4[r]);
+                acc_set(y[1][0][mt][r], b4[r]);
+                acc_set(y[1][1][mt][r], b4[r]);
+            }
         }
 
         // ---- main loop: nu > chunk > xi, one flat software pipeline -----------------------------
@@ -239,6 +257,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f32_wino_kernel(Conv3x3Args a,
                 // next chunk (this nu's, the next nu's first, or the next item's first) -> other buffers
 #pragma unroll
                 for (int xi = 0; xi < 4; ++xi) {
+                    if (nu == 1 && chunk == 2) { if (xi == 0) C3W_STAMP(10); if (xi == 1) C3W_STAMP(12); if (xi == 3) C3W_STAMP(13); }
                     if (xi < 3) {
                         // next chunk (this nu's, the next nu's first, or the next item's first) -> other buffers
                         if (!last_of_item) stage(cur, chunk < 5 ? nu : nu_next, chunk < 5 ? chunk + 1 : 0, buf ^ 1, xi);
@@ -248,6 +267,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f32_wino_kernel(Conv3x3Args a,
                     } else {
                         // the next buffers (halo chunk + U slab) were issued three xi steps ago
                         __syncthreads();
+                        if (nu == 1 && chunk == 2) C3W_STAMP(14);
                         if (more) {
                             load_u(ua, buf ^ 1, 0);
                             if (chunk < 5) read_raw(R, nu, buf ^ 1);
@@ -255,6 +275,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f32_wino_kernel(Conv3x3Args a,
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
+                    if (nu == 1 && chunk == 2 && xi == 0) C3W_STAMP(11);
                     const UF& u = (xi & 1) ? ub : ua;
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
@@ -265,6 +286,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f32_wino_kernel(Conv3x3Args a,
                         else combine(V, R, nu_next);
                     }
                 }
+                if (nu == 1 && chunk == 2) C3W_STAMP(15);
             }
             C3W_STAMP(1 + 2 * nu);
             // fold into the outputs: T_i = sum_xi At[i][xi] M[xi],  At = [[1,1,1,0],[0,1,-1,-1]];
@@ -273,9 +295,21 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f32_wino_kernel(Conv3x3Args a,
             for (int mt = 0; mt < 6; ++mt) {
                 const f32x4 T0 = M[0][mt] + M[1][mt] + M[2][mt];
                 const f32x4 T1 = M[1][mt] - M[2][mt] - M[3][mt];
-                if (nu <= 2) { y[0][0][mt] += T0; y[1][0][mt] += T1; }
-                if (nu == 1) { y[0][1][mt] += T0; y[1][1][mt] += T1; }
-                if (nu >= 2) { y[0][1][mt] -= T0; y[1][1][mt] -= T1; }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (nu <= 2) {
+                        acc_set(y[0][0][mt][r], acc_get(y[0][0][mt][r]) + T0[r]);
+                        acc_set(y[1][0][mt][r], acc_get(y[1][0][mt][r]) + T1[r]);
+                    }
+                    if (nu == 1) {
+                        acc_set(y[0][1][mt][r], acc_get(y[0][1][mt][r]) + T0[r]);
+                        acc_set(y[1][1][mt][r], acc_get(y[1][1][mt][r]) + T1[r]);
+                    }
+                    if (nu >= 2) {
+                        acc_set(y[0][1][mt][r], acc_get(y[0][1][mt][r]) - T0[r]);
+                        acc_set(y[1][1][mt][r], acc_get(y[1][1][mt][r]) - T1[r]);
+                    }
+                }
             }
             C3W_STAMP(2 + 2 * nu);
         };
@@ -288,6 +322,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f32_wino_kernel(Conv3x3Args a,
         // ---- epilogue: PReLU -> (+ residual) -> 16-byte NHWC stores ------------------------------
         const int oy = cur.ty * 4 + 2 * tr, ox = cur.tx * 64 + 2 * tt;
         f32x4 psum[6];
+        f32x4 rr[RES ? 24 : 1];          // the residual of all 4 pixels in flight at once (M's registers are free)
+        if (RES) {
+#pragma unroll
+            for (int q = 0; q < 24; ++q)
+                rr[RES ? q : 0] = *(const f32x4*)((const float*)a.res + (((size_t)cur.n * HW + oy + q / 12) * HW + ox + ((q / 6) & 1)) * kC + 4 * kq + 16 * (q % 6));
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -297,21 +337,17 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f32_wino_kernel(Conv3x3Args a,
                     out += (((size_t)cur.n * 2 * HW + 2 * (oy + i) + (cur.cb >> 1)) * 2 * HW + 2 * (ox + j) + (cur.cb & 1)) * kC + 4 * kq;
                 else
                     out += (((size_t)cur.n * HW + oy + i) * HW + ox + j) * kC + 4 * kq;
-                f32x4 rr[6];
-                if (RES) {
-                    const float* res = (const float*)a.res + (((size_t)cur.n * HW + oy + i) * HW + ox + j) * kC + 4 * kq;
-#pragma unroll
-                    for (int mt = 0; mt < 6; ++mt) rr[mt] = *(const f32x4*)(res + 16 * mt);
-                }
 #pragma unroll
                 for (int mt = 0; mt < 6; ++mt) {
-                    f32x4 v = y[i][j][mt];
+                    f32x4 v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = acc_get(y[i][j][mt][r]);
                     if (ACT) {
                         const f32x4 s4 = *(const f32x4*)(ldsSlope + cur.cb * 96 + 16 * mt + 4 * kq);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.f ? v[e] : v[e] * s4[e];
                     }
-                    if (RES) v += rr[mt];
+                    if (RES) v += rr[RES ? (i * 2 + j) * 6 + mt : 0];
                     if (POOL) psum[mt] = (i == 0 && j == 0) ? v : psum[mt] + v;
                     *(f32x4*)(out + 16 * mt) = v;
                 }

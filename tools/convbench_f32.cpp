@@ -58,9 +58,10 @@ int main(int argc, char** argv)
     std::mt19937 rng(123);
     std::uniform_real_distribution<float> U(-1.f, 1.f);
     std::vector<float> h_in(in_elems), h_res(in_elems), h_w(w_elems);
-    for (auto& v : h_in) v = U(rng);
+    const bool zero_data = getenv("C3_ZERO") != nullptr;      // all-zero operands: clock stays high (power test)
+    for (auto& v : h_in) v = zero_data ? 0.f : U(rng);
     for (auto& v : h_res) v = U(rng);
-    for (auto& v : h_w) v = 0.06f * U(rng);
+    for (auto& v : h_w) v = zero_data ? 0.f : 0.06f * U(rng);
     std::vector<float> h_bias(96 * cb), h_slope(96 * cb);
     for (auto& v : h_bias) v = 0.1f * U(rng);
     for (auto& v : h_slope) v = 0.25f + 0.2f * U(rng);
@@ -216,6 +217,15 @@ int main(int argc, char** argv)
             for (size_t i = 0; i < nit; ++i) d.push_back(st[i * 16 + k + 1] - st[i * 16 + k]);
             std::sort(d.begin(), d.end());
             printf("  %-10s median %7lld  p10 %7lld  p90 %7lld ticks\n", names[k], d[d.size() / 2], d[d.size() / 10], d[d.size() * 9 / 10]);
+        }
+        {
+            const char* nm[5] = {"top->stage+loadu issued", "xi0 mfma issue", "xi1+xi2 (to barrier)", "barrier", "xi3 + combine"};
+            for (int k = 0; k < 5; ++k) {
+                std::vector<long long> d;
+                for (size_t i = 0; i < nit; ++i) d.push_back(st[i * 16 + 11 + k] - st[i * 16 + 10 + k]);
+                std::sort(d.begin(), d.end());
+                printf("  chunk(nu1,c2) %-26s median %6lld  p10 %6lld  p90 %6lld\n", nm[k], d[d.size() / 2], d[d.size() / 10], d[d.size() * 9 / 10]);
+            }
         }
         void* nul = nullptr;
         CK(hipMemcpyToSymbol(HIP_SYMBOL(c3w::g_wstamps), &nul, sizeof(nul)));
