@@ -55,9 +55,10 @@ constexpr int ROWB = 64 * ENTRY;                                    // 4,096
 constexpr int EDGE_OFF = IN_ROWS * ROWB;                            // 24,576
 constexpr int BUF_BYTES = EDGE_OFF + 1024;                          // 25,600 (edge piece = one wave piece, 768 B used)
 constexpr int USLAB_BYTES = 4 * 4 * 96 * 16;                        // 24,576: U of one (nu, chunk): [xi][ci/4][co] float4
-constexpr int U_OFF = 2 * BUF_BYTES;                                // two U slabs behind the two halo buffers
-constexpr int BS_OFF = U_OFF + 2 * USLAB_BYTES;                     // bias[4][96], slope[4][96]
-constexpr int LDS_BYTES = BS_OFF + 2 * 4 * 96 * 4;                  // 103,424 (one workgroup per CU)
+constexpr int NBUF = 3;                                             // chunk c+2 is staged while chunk c is multiplied
+constexpr int U_OFF = NBUF * BUF_BYTES;                             // the U slabs sit behind the halo buffers
+constexpr int BS_OFF = U_OFF + NBUF * USLAB_BYTES;                     // bias[4][96], slope[4][96]
+constexpr int LDS_BYTES = BS_OFF + 2 * 4 * 96 * 4;                  // 153,600 (one workgroup per CU)
 constexpr int MAX_WGS = 256;                      // persistent grid: one workgroup per CU
 
 __device__ __forceinline__ int opaque(int v)
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f32_wino_kernel(Conv3x3Args a,
     // piece of halo row k is its own fixed 16 bytes of that row's 64-pixel segment (byte offset
     // row_off); rows outside the image come from the zero page (kWinoZeroBytes) at the same offset.
     constexpr bool EDGES = tiles_x > 1;            // with one tile per image row both edge columns are padding
-    if (!EDGES && tid < 128) {                     // ... zeroed once, never staged
+    if (!EDGES && tid < 64 * NBUF) {               // ... zeroed once, never staged
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
         *(f32x4*)(lds + (tid >> 6) * BUF_BYTES + EDGE_OFF + (tid & 63) * 16) = z;
     }
@@ -209,6 +210,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f32_wino_kernel(Conv3x3Args a,
 
     Item cur = decode(item);
     stage(cur, 0, 0, 0, -1);
+    stage(cur, 0, 1, 1, -1);
     __syncthreads();
 
     // pipeline registers: V of the current chunk, raw halo reads of the next, U fragments of the
@@ -251,31 +253,34 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f32_wino_kernel(Conv3x3Args a,
                 for (int mt = 0; mt < 6; ++mt) M[xi][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
             for (int chunk = 0; chunk < 6; ++chunk) {
-                const int buf = (nu * 6 + chunk) & 1;
-                const bool last_of_item = nu == 3 && chunk == 5;
-                const bool more = !last_of_item || has_next;
-                // next chunk (this nu's, the next nu's first, or the next item's first) -> other buffers
+                // chunk sequence number s = nu*6 + chunk lives in buffer s % 3 = chunk % 3; s + 1 is being
+                // read ahead at xi = 3, s + 2 is staged (this nu's, the next nu's, or the next item's: nx is
+                // this item again after the last one, a harmless re-stage that keeps the vmcnt arithmetic)
+                const int buf = chunk >= 3 ? chunk - 3 : chunk;
+                const int bufn = buf == 2 ? 0 : buf + 1, bufs = bufn == 2 ? 0 : bufn + 1;
+                constexpr bool more = true;
 #pragma unroll
                 for (int xi = 0; xi < 4; ++xi) {
-                    if (nu == 1 && chunk == 2) { if (xi == 0) C3W_STAMP(10); if (xi == 1) C3W_STAMP(12); if (xi == 3) C3W_STAMP(13); }
                     if (xi < 3) {
                         // next chunk (this nu's, the next nu's first, or the next item's first) -> other buffers
-                        if (!last_of_item) stage(cur, chunk < 5 ? nu : nu_next, chunk < 5 ? chunk + 1 : 0, buf ^ 1, xi);
-                        else if (has_next) stage(nx, 0, 0, buf ^ 1, xi);
+                        if (chunk < 4) stage(cur, nu, chunk + 2, bufs, xi);
+                        else if (nu < 3) stage(cur, nu_next, chunk - 4, bufs, xi);
+                        else stage(nx, 0, chunk - 4, bufs, xi);
                         if (xi & 1) load_u(ua, buf, xi + 1);
                         else load_u(ub, buf, xi + 1);
                     } else {
-                        // the next buffers (halo chunk + U slab) were issued three xi steps ago
-                        __syncthreads();
-                        if (nu == 1 && chunk == 2) C3W_STAMP(14);
-                        if (more) {
-                            load_u(ua, buf ^ 1, 0);
-                            if (chunk < 5) read_raw(R, nu, buf ^ 1);
-                            else read_raw(R, nu_next, buf ^ 1);
-                        }
+                        // chunk s+1 was staged a whole chunk ago: wait for it only -- the 12 pieces this wave
+                        // issued for s+2 during this chunk stay in flight (vmcnt counts in order) -- and
+                        // for this wave's LDS reads of the buffer that s+3 will overwrite.
+                        asm volatile("" ::: "memory");
+                        __builtin_amdgcn_s_waitcnt(0x0070 | 12);      // vmcnt(12) lgkmcnt(0)
+                        __builtin_amdgcn_s_barrier();
+                        asm volatile("" ::: "memory");
+                        load_u(ua, bufn, 0);
+                        if (chunk < 5) read_raw(R, nu, bufn);
+                        else read_raw(R, nu_next, bufn);
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    if (nu == 1 && chunk == 2 && xi == 0) C3W_STAMP(11);
                     const UF& u = (xi & 1) ? ub : ua;
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
@@ -286,7 +291,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f32_wino_kernel(Conv3x3Args a,
                         else combine(V, R, nu_next);
                     }
                 }
-                if (nu == 1 && chunk == 2) C3W_STAMP(15);
             }
             C3W_STAMP(1 + 2 * nu);
             // fold into the outputs: T_i = sum_xi At[i][xi] M[xi],  At = [[1,1,1,0],[0,1,-1,-1]];
@@ -354,10 +358,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f32_wino_kernel(Conv3x3Args a,
             }
         if (POOL) {
             // per-item channel sums (ChannelAttention's pool), fixed order: xor butterfly over the 16
-            // tile lanes of each kq group, then the 4 waves through LDS.  P sits in halo buffer 1: the
+            // tile lanes of each kq group, then the 4 waves through LDS.  P sits in halo buffer 2: the
             // item's last chunk (sequence 23) used it and every wave is past that chunk's barrier and
-            // V reads; buffer 0 is being filled for the next item.
-            float* P = (float*)(lds + BUF_BYTES);
+            // V reads; buffers 0 and 1 hold / receive the next item's first chunks.
+            float* P = (float*)(lds + 2 * BUF_BYTES);
             __syncthreads();
 #pragma unroll
             for (int mt = 0; mt < 6; ++mt) {
@@ -380,6 +384,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f32_wino_kernel(Conv3x3Args a,
         item = nxt;
         cur = nx;
     }
+    __syncthreads();        // the last chunks' (unused) staging must land before the LDS is released
 }
 
 template <int HW, bool SHUFFLE, bool POOL, bool RES, bool ACT>
