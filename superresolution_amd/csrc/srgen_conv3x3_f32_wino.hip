@@ -273,7 +273,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f32_wino_kernel(Conv3x3Args a,
                         // issued for s+2 during this chunk stay in flight (vmcnt counts in order) -- and
                         // for this wave's LDS reads of the buffer that s+3 will overwrite.
                         asm volatile("" ::: "memory");
-                        __builtin_amdgcn_s_waitcnt(0x0070 | 12);      // vmcnt(12) lgkmcnt(0)
+                        // (the first barrier of nu = 3 also leaves the 24 residual loads in flight, which
+                        // were issued just before this chunk's staging: vmcnt(36))
+                        if (RES && nu == 3 && chunk == 0) __builtin_amdgcn_s_waitcnt(0x8074);
+                        else __builtin_amdgcn_s_waitcnt(0x0070 | 12);     // vmcnt(12) lgkmcnt(0)
                         __builtin_amdgcn_s_barrier();
                         asm volatile("" ::: "memory");
                         load_u(ua, bufn, 0);
@@ -321,17 +324,18 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f32_wino_kernel(Conv3x3Args a,
         run_nu(std::integral_constant<int, 0>{});
         run_nu(std::integral_constant<int, 1>{});
         run_nu(std::integral_constant<int, 2>{});
-        run_nu(std::integral_constant<int, 3>{});
-
-        // ---- epilogue: PReLU -> (+ residual) -> 16-byte NHWC stores ------------------------------
+        // the residual of the lane's 4 pixels: in flight under the whole nu = 3 pass
         const int oy = cur.ty * 4 + 2 * tr, ox = cur.tx * 64 + 2 * tt;
-        f32x4 psum[6];
-        f32x4 rr[RES ? 24 : 1];          // the residual of all 4 pixels in flight at once (M's registers are free)
+        f32x4 rr[RES ? 24 : 1];
         if (RES) {
 #pragma unroll
             for (int q = 0; q < 24; ++q)
                 rr[RES ? q : 0] = *(const f32x4*)((const float*)a.res + (((size_t)cur.n * HW + oy + q / 12) * HW + ox + ((q / 6) & 1)) * kC + 4 * kq + 16 * (q % 6));
         }
+        run_nu(std::integral_constant<int, 3>{});
+
+        // ---- epilogue: PReLU -> (+ residual) -> 16-byte NHWC stores ------------------------------
+        f32x4 psum[6];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
