@@ -90,6 +90,30 @@ __global__ __launch_bounds__(256) void kf32(const float* in, float* out, long lo
     if (tid == 0) ticks[blockIdx.x] = t1 - t0;
 }
 
+// v_mfma_f32_16x16x4_f32 with NACC independent accumulators (the Winograd kernel's shape: 24)
+template <int NACC>
+__global__ __launch_bounds__(256) void kf32_16(const float* in, float* out, long long* ticks, int iters)
+{
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x;
+    float a[6], b[4];
+    for (int i = 0; i < 6; ++i) a[i] = in[tid + 256 * i];
+    for (int i = 0; i < 4; ++i) b[i] = in[tid + 17 * i];
+    f32x4 c[NACC];
+    for (int i = 0; i < NACC; ++i) c[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    const long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) c[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i % 6], b[i % 4], c[i], 0, 0, 0);
+    }
+    const long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0;
+    for (int i = 0; i < NACC; ++i) for (int r = 0; r < 4; ++r) s += c[i][r];
+    out[blockIdx.x * 256 + tid] = s;
+    if (tid == 0) ticks[blockIdx.x] = t1 - t0;
+}
+
 int main()
 {
     bf16x8* in; float* out; long long* ticks;
@@ -129,6 +153,23 @@ int main()
         std::sort(t.begin(), t.end());
         const double nm = 6.0 * iters, flop = (double)wgs * 4 * nm * 4096.0;
         printf("f32 32x32x2  %4d WGs: median %.1f ticks/MFMA per wave, %.3f ms, %.1f TFLOP/s, clock~%.2f GHz\n", wgs,
+               t[wgs / 2] / nm, ms, flop / ms * 1e-9, t[wgs / 2] / (ms * 1e6));
+    }
+    for (int nacc : {24, 6}) {
+        const int wgs = 256;
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        for (int rep = 0; rep < 2; ++rep) {
+            hipEventRecord(e0);
+            if (nacc == 24) hipLaunchKernelGGL(kf32_16<24>, dim3(wgs), dim3(256), 0, 0, (const float*)in, out, ticks, iters);
+            else hipLaunchKernelGGL(kf32_16<6>, dim3(wgs), dim3(256), 0, 0, (const float*)in, out, ticks, iters * 4);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+        }
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        std::vector<long long> t(wgs);
+        hipMemcpy(t.data(), ticks, wgs * 8, hipMemcpyDeviceToHost);
+        std::sort(t.begin(), t.end());
+        const double nm = 24.0 * iters, flop = (double)wgs * 4 * nm * 2048.0;
+        printf("f32 16x16x4 (%2d accumulators) %4d WGs: median %.1f ticks/MFMA per wave, %.3f ms, %.1f TFLOP/s, clock~%.2f GHz\n", nacc, wgs,
                t[wgs / 2] / nm, ms, flop / ms * 1e-9, t[wgs / 2] / (ms * 1e6));
     }
     return 0;
