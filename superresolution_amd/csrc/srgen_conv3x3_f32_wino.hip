@@ -75,6 +75,13 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base)
 
 struct Item { int n, ty, tx, cb; };
 
+// acc += a (x) b on v_mfma_f32_16x16x4_f32, accumulator in place by construction: through the builtin
+// the register allocator is free to rotate loop-carried accumulators through copies.
+__device__ __forceinline__ void mfma_acc(f32x4& acc, float a, float b)
+{
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+
 // The 2x2 output accumulators are touched only by the four folds and the epilogue of an item, but
 // are live across all of its 2,304 MFMAs; left to the register allocator they compete with the
 // pipeline registers for the 256 architectural VGPRs and spill.  Pin them to the accumulator half
@@ -258,16 +265,29 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f32_wino_kernel(Conv3x3Args a,
                 // this item again after the last one, a harmless re-stage that keeps the vmcnt arithmetic)
                 const int buf = chunk >= 3 ? chunk - 3 : chunk;
                 const int bufn = buf == 2 ? 0 : buf + 1, bufs = bufn == 2 ? 0 : bufn + 1;
-                constexpr bool more = true;
+                // LDS addresses of this chunk's reads, formed here so that nothing but the reads
+                // themselves (address register + immediate offset) sits between the MFMAs below
+                const int u_lane = (kq * 96 + c16) * 16;
+                const int ua_cur = opaque(U_OFF + buf * USLAB_BYTES + u_lane);
+                const int ua_nxt = opaque(U_OFF + bufn * USLAB_BYTES + u_lane);
+                int va[8];                                                  // va[2r + which], chunk read ahead at xi = 3
+                auto set_va = [&](int nuc) {
+                    const int b0 = nuc == 0 ? 0 : 1, b1 = nuc == 3 ? 3 : 2;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        va[2 * r] = opaque(bufn * BUF_BYTES + rb[b0] + r * (b0 == 1 ? ROWB : rs[b0]));
+                        va[2 * r + 1] = opaque(bufn * BUF_BYTES + rb[b1] + r * (b1 == 2 ? ROWB : rs[b1]));
+                    }
+                };
+                if (chunk < 5) set_va(nu);
+                else set_va(nu_next);
 #pragma unroll
                 for (int xi = 0; xi < 4; ++xi) {
                     if (xi < 3) {
-                        // next chunk (this nu's, the next nu's first, or the next item's first) -> other buffers
+                        // chunk s+2 -> the third buffer pair
                         if (chunk < 4) stage(cur, nu, chunk + 2, bufs, xi);
                         else if (nu < 3) stage(cur, nu_next, chunk - 4, bufs, xi);
                         else stage(nx, 0, chunk - 4, bufs, xi);
-                        if (xi & 1) load_u(ua, buf, xi + 1);
-                        else load_u(ub, buf, xi + 1);
                     } else {
                         // chunk s+1 was staged a whole chunk ago: wait for it only -- the 12 pieces this wave
                         // issued for s+2 during this chunk stay in flight (vmcnt counts in order) -- and
@@ -279,22 +299,34 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f32_wino_kernel(Conv3x3Args a,
                         else __builtin_amdgcn_s_waitcnt(0x0070 | 12);     // vmcnt(12) lgkmcnt(0)
                         __builtin_amdgcn_s_barrier();
                         asm volatile("" ::: "memory");
-                        load_u(ua, bufn, 0);
-                        if (chunk < 5) read_raw(R, nu, bufn);
-                        else read_raw(R, nu_next, bufn);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     const UF& u = (xi & 1) ? ub : ua;
+                    UF& un = (xi & 1) ? ua : ub;
+                    // 24 MFMAs with ONE LDS read in every fourth gap: there a ds_read_b128 issues for
+                    // free, in a cluster in front of the block each costs ~30 cycles of an idle matrix
+                    // pipe (tools/issuebench.cpp).  xi 0..2: the U fragments of xi+1; xi 3: the raw halo
+                    // reads and the first U fragments of the next chunk.
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-#pragma unroll
-                        for (int mt = 0; mt < 6; ++mt) M[xi][mt] = MFMA16_F32(u.u[mt][e], V[xi][e], M[xi][mt]);
-                    if (xi == 3 && more) {
+                    for (int sl = 0; sl < 24; ++sl) {
+                        const int e = sl / 6, mt = sl % 6;
+                        mfma_acc(M[xi][mt], u.u[mt][e], V[xi][e]);
+                        if (xi < 3) {
+                            if (sl % 4 == 1) un.u[sl / 4] = *(const f32x4*)(lds + ua_cur + ((xi + 1) * 4 * 96 + 16 * (sl / 4)) * 16);
+                        } else {
+                            if (sl < 16 && sl % 2 == 1) R[sl / 2] = *(const f32x4*)(lds + va[sl / 2]);
+                            if (sl >= 16 && sl < 22) ua.u[sl - 16] = *(const f32x4*)(lds + ua_nxt + 16 * (sl - 16) * 16);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (xi == 3) {
                         if (chunk < 5) combine(V, R, nu);
                         else combine(V, R, nu_next);
                     }
                 }
             }
+            // the asm MFMAs are opaque to the hazard recognizer: let the last ones retire before M is read
+            asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
             C3W_STAMP(1 + 2 * nu);
             // fold into the outputs: T_i = sum_xi At[i][xi] M[xi],  At = [[1,1,1,0],[0,1,-1,-1]];
             // y[i][0] += T_i for nu = 0,1,2;  y[i][1] += T_i (nu 1), -= T_i (nu 2, 3).
