@@ -215,10 +215,61 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f32_wino_kernel(Conv3x3Args a,
         for (int mt = 0; mt < 6; ++mt) u.u[mt] = p[16 * mt];
     };
 
+    // In the main loop the staging of chunk s+2 is issued as three clusters of four wave pieces in front
+    // of the MFMA blocks of xi = 0, 1, 2.  A global_load_lds costs ~30 cycles of an idle matrix pipe by
+    // itself (tools/issuebench.cpp) and as much again for the scalar address arithmetic in front of it,
+    // so that arithmetic is done one block earlier, in MFMA gaps, into four piece descriptors
+    // (source row / slab pointer and LDS destination, both wave-uniform); a cluster is then nothing
+    // but 4 x {s_mov m0, global_load_lds}.  Pieces g = 0..5: halo rows, 6..11: the U slab.
+    struct Stage { const char* in; const char* usrc; int dst, udst, y0, x0; };
+    auto make_stage = [&](const Item& it, int nu, int chunk, int buf) {
+        Stage st;
+        st.in = (const char*)((const float*)a.in + ((size_t)it.n * HW * HW + it.tx * 64) * kC + chunk * CK);
+        st.usrc = (const char*)a.wpack + (size_t)((it.cb * 4 + nu) * 6 + chunk) * USLAB_BYTES;
+        st.dst = buf * BUF_BYTES + w * 1024;
+        st.udst = U_OFF + buf * USLAB_BYTES + w * 1024;
+        st.y0 = it.ty * 4 - 1;
+        st.x0 = it.tx * 64;
+        return st;
+    };
+    const char* d_src[4];
+    int d_dst[4];
+    auto make_desc = [&](const Stage& st, int g, int j) {
+        const char* sp;
+        int dm;
+        if (g < IN_ROWS) {
+            const int gy = st.y0 + g;
+            sp = (unsigned)gy < (unsigned)HW ? st.in + (size_t)gy * (HW * kC * 4) : (const char*)a.zeros;
+            dm = st.dst + g * ROWB;
+        } else {
+            sp = st.usrc + (g - IN_ROWS) * 4096;
+            dm = st.udst + (g - IN_ROWS) * 4096;
+        }
+        asm volatile("" : "+s"(sp), "+s"(dm));       // computed HERE (an MFMA gap), not at the use
+        d_src[j] = sp;
+        d_dst[j] = dm;
+    };
+    auto issue_piece = [&](int g, int j) {
+        const unsigned voff = (unsigned)opaque(g < IN_ROWS ? row_off : tid * 16);
+        glds16(d_src[j] + voff, lds + d_dst[j]);
+    };
+    auto issue_edge = [&](const Stage& st) {        // edge columns (tiles_x > 1 only), wave 0
+        if (EDGES && w == 0) {
+            const int l = opaque(lane);
+            const int gy = st.y0 + (l >> 3), dx = ((l >> 2) & 1) ? 64 : -1, gx = st.x0 + dx;
+            const bool ok = l < 48 && (unsigned)gy < (unsigned)HW && (unsigned)gx < (unsigned)HW;
+            const char* src = ok ? st.in + ((ptrdiff_t)gy * HW + dx) * (kC * 4) + (l & 3) * 16 : (const char*)a.zeros;
+            glds16(src, lds + st.dst + EDGE_OFF);     // st.dst includes w*1024 = 0
+        }
+    };
+
     Item cur = decode(item);
     stage(cur, 0, 0, 0, -1);
     stage(cur, 0, 1, 1, -1);
     __syncthreads();
+    Stage st = make_stage(cur, 0, 2, 2);           // staging target of the first chunk iteration
+#pragma unroll
+    for (int j = 0; j < 4; ++j) make_desc(st, j, j);
 
     // pipeline registers: V of the current chunk, raw halo reads of the next, U fragments of the
     // current and the next xi
@@ -285,9 +336,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f32_wino_kernel(Conv3x3Args a,
                 for (int xi = 0; xi < 4; ++xi) {
                     if (xi < 3) {
                         // chunk s+2 -> the third buffer pair
-                        if (chunk < 4) stage(cur, nu, chunk + 2, bufs, xi);
-                        else if (nu < 3) stage(cur, nu_next, chunk - 4, bufs, xi);
-                        else stage(nx, 0, chunk - 4, bufs, xi);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) issue_piece(4 * xi + j, j);
+                        if (xi == 1) issue_edge(st);
                     } else {
                         // chunk s+1 was staged a whole chunk ago: wait for it only -- the 12 pieces this wave
                         // issued for s+2 during this chunk stay in flight (vmcnt counts in order) -- and
@@ -313,6 +364,15 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f32_wino_kernel(Conv3x3Args a,
                         mfma_acc(M[xi][mt], u.u[mt][e], V[xi][e]);
                         if (xi < 3) {
                             if (sl % 4 == 1) un.u[sl / 4] = *(const f32x4*)(lds + ua_cur + ((xi + 1) * 4 * 96 + 16 * (sl / 4)) * 16);
+                            // descriptors of the next cluster (scalar work, free in these gaps)
+                            if (xi < 2 && sl % 6 == 2) make_desc(st, 4 * (xi + 1) + sl / 6, sl / 6);
+                            if (xi == 2 && sl == 2) {
+                                // the next chunk iteration stages ITS s+2 into the buffer this one is reading
+                                if (chunk < 3) st = make_stage(cur, nu, chunk + 3, buf);
+                                else if (chunk < 5) st = nu < 3 ? make_stage(cur, nu_next, chunk - 3, buf) : make_stage(nx, 0, chunk - 3, buf);
+                                else st = nu < 3 ? make_stage(cur, nu_next, 2, buf) : make_stage(nx, 0, 2, buf);
+                            }
+                            if (xi == 2 && sl >= 8 && sl % 4 == 0 && sl / 4 - 2 < 4) make_desc(st, sl / 4 - 2, sl / 4 - 2);
                         } else {
                             if (sl < 16 && sl % 2 == 1) R[sl / 2] = *(const f32x4*)(lds + va[sl / 2]);
                             if (sl >= 16 && sl < 22) ua.u[sl - 16] = *(const f32x4*)(lds + ua_nxt + 16 * (sl - 16) * 16);
