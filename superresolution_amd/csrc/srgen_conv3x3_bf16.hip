@@ -32,6 +32,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef C3_IL
+#define C3_IL 1        // fragment reads interleaved one per MFMA gap (0: clustered in front of each step)
+#endif
 #define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
 
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
@@ -99,6 +102,31 @@ __device__ __forceinline__ void mma_step(f32x16 (&acc)[2][3], const Frags& f)
     acc[1][2] = MFMA_BF16(f.b2, f.a1, acc[1][2]);
 }
 
+// One k16-step with the five fragment reads of the NEXT step in the gaps between its six MFMAs: a
+// ds_read_b128 issued alone between two MFMAs costs nothing, five in a row in front of the block stall
+// the wave -- and with it this SIMD's share of the matrix pipe -- for ~30 cycles each
+// (tools/issuebench.cpp).  Read order = use order, so every fragment has five MFMAs to arrive.
+__device__ __forceinline__ void mma_step_il(f32x16 (&acc)[2][3], const Frags& f, Frags& n, const char* Ab, const char* Bb,
+                                            int g, bool next)
+{
+    acc[0][0] = MFMA_BF16(f.b0, f.a0, acc[0][0]);
+    if (next) n.b0 = *(const bf16x8*)(Bb + (2 * g * 96) * 16);
+    __builtin_amdgcn_sched_barrier(0);
+    acc[1][0] = MFMA_BF16(f.b0, f.a1, acc[1][0]);
+    if (next) n.a0 = *(const bf16x8*)(Ab + g * 32);
+    __builtin_amdgcn_sched_barrier(0);
+    acc[0][1] = MFMA_BF16(f.b1, f.a0, acc[0][1]);
+    if (next) n.a1 = *(const bf16x8*)(Ab + 32 * PS + g * 32);
+    __builtin_amdgcn_sched_barrier(0);
+    acc[1][1] = MFMA_BF16(f.b1, f.a1, acc[1][1]);
+    if (next) n.b1 = *(const bf16x8*)(Bb + (2 * g * 96 + 32) * 16);
+    __builtin_amdgcn_sched_barrier(0);
+    acc[0][2] = MFMA_BF16(f.b2, f.a0, acc[0][2]);
+    if (next) n.b2 = *(const bf16x8*)(Bb + (2 * g * 96 + 64) * 16);
+    __builtin_amdgcn_sched_barrier(0);
+    acc[1][2] = MFMA_BF16(f.b2, f.a1, acc[1][2]);
+}
+
 // Returns v, but opaque to the optimiser: index arithmetic derived from it is recomputed where it
 // is used instead of being hoisted out of the persistent loop and kept in (spilled) registers.
 __device__ __forceinline__ int opaque(int v)
@@ -151,6 +179,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(Conv3x3Args a, int
     float* const ldsBias = (float*)(lds + BS_OFF);
     float* const ldsSlope = ldsBias + 4 * 96;
 
+    const int tid16 = tid * 16;
     u32x4 stage[10];
     auto load_a = [&](const Item& t, int c) {
 #if defined(C3_NOMEM) && (C3_NOMEM & 1)      // development: always the same (L2-resident) tile
@@ -192,10 +221,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(Conv3x3Args a, int
         const int tap = j % 9, c = j / 9;
         const char* src = (const char*)a.wpack + ((size_t)((cb * 9 + tap) * 12 + 6 * c) * 96) * 16;
         char* dst = ldsB + (j % NRING) * SLAB;
-        const int tv = opaque(tid);
-        glds16(src + tv * 16, dst + w * 1024);
-        glds16(src + (256 + tv) * 16, dst + (256 + w * 64) * 16);
-        if (lane < 16) glds16(src + (512 + w * 16 + (tv & 63)) * 16, dst + (512 + w * 16) * 16);
+        // wave-uniform base + one per-lane 32-bit offset: global_load_lds v_off, s[base] with no vector
+        // address arithmetic in the MFMA stream (a VALU instruction between MFMAs costs ~28 cycles);
+        // the 64-unit tail of the slab is wave 0's alone (a scalar branch) instead of 16 lanes of each wave
+        glds16(src + (unsigned)opaque(tid16), dst + w * 1024);
+        glds16(src + 4096 + (unsigned)opaque(tid16), dst + 4096 + w * 1024);
+        if (w == 0) glds16(src + 8192 + (unsigned)opaque(tid16), dst + 8192);
     };
     // Residual of this lane's outputs: pixel (y0 + w, x0 + 32*mt + p); per accumulator tile
     // (mt, nt) two 16-byte pieces P = 0, 1 at channels 32*nt + 16*P + 8*h (see the epilogue).
@@ -276,6 +307,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(Conv3x3Args a, int
                     if (tap == 8 && c == 0) load_a(cur, 1);
                     if (RES && tap == 7 && c == 1) load_res(cur);
                 }
+#if C3_IL
+                {
+                    const int tap1 = (s + 1) / 3, g1 = (s + 1) % 3;
+                    const int dy = tap1 / 3, dx = tap1 % 3;
+                    const char* Ab = Aw + (dy * HWP + dx) * PS;
+                    const char* Bb = Bw + ((c * 9 + tap1) % NRING) * SLAB;
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (s & 1) mma_step_il(acc, f1, f0, Ab, Bb, g1, s + 1 < 27);
+                    else mma_step_il(acc, f0, f1, Ab, Bb, g1, s + 1 < 27);
+                }
+#else
                 if (s + 1 < 27) {
                     const int tap1 = (s + 1) / 3, g1 = (s + 1) % 3;
                     const int dy = tap1 / 3, dx = tap1 % 3;
@@ -285,6 +327,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(Conv3x3Args a, int
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (s & 1) mma_step(acc, f1); else mma_step(acc, f0);
+#endif
                 if (g == 2) __syncthreads();       // slabs j+1, j+2 landed; slab j is free
             }
         };
