@@ -185,7 +185,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: Generator eval inference (BN folded), "
+            "config": {"workload": f"BASELINE.json configs[{1 if args.dtype == 'f32' else 2}]"
+                                   f"{'' if args.dtype == 'f32' else ' (its bf16 path, one 256-image batch per GPU)'}: "
+                                   "Generator eval inference (BN folded), "
                                    f"batch {args.batch} of 3x64x64 per GPU -> 3x125x125, {args.dtype}",
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"batch-sharded x{world}, weights replicated"},

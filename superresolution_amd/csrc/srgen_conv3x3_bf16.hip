@@ -6,20 +6,25 @@
 // (upsample conv, PixelShuffle :8 folded into the store address), :69 (output[0]); PReLU
 // :36,:9,:70 and the residual adds :42,:78 are the epilogue.
 //
-// Structure (one workgroup = 4 waves = 4 rows x 64 pixels x 96 output channels; two workgroups
-// per CU so one workgroup's prologue / epilogue is covered by the other's MFMAs):
-//   * GEMM view: M = pixels, N = 96 co, K = 9 taps x 96 ci, walked as 2 ci-chunks x 9 taps x
-//     3 k16-steps = 54 steps of 6 MFMAs per wave;
-//   * A (activations): zero-padded 6 x 66 pixel halo tile of one 48-ci chunk in LDS, pixel
-//     stride 112 B (7 x 16 B, odd => conflict-free ds_read_b128); chunk 1 is fetched into
-//     registers under the last tap of chunk 0;
-//   * B (weights): one 9 KB slab per (tap, chunk) copied global -> LDS with global_load_lds
-//     into a 3-deep ring, issued two phases ahead, so the fragments of the next phase's first
-//     step can be read before the barrier that ends the current phase;
-//   * fragments are double-buffered in registers: the ds_reads of step s+1 are issued before
-//     the MFMAs of step s (the compiler alone serialises read -> wait -> MFMA);
-//   * epilogue: bias -> PReLU -> fp32 transpose through LDS -> (+ residual) -> 16-byte
-//     row-contiguous bf16 stores; optional per-tile channel sums for ChannelAttention's pool.
+// Structure (one workgroup = 4 waves = 4 rows x 64 pixels x 96 output channels; persistent, two
+// workgroups per CU, de-phased at start so one's prologue / epilogue is covered by the other's MFMAs):
+//   * GEMM view: M = 96 co (the MFMA A operand: weights), N = pixels (B operand), K = 9 taps x 96 ci,
+//     walked as 2 ci-chunks x 9 taps x 3 k16-steps = 54 steps of 6 MFMAs per wave; the accumulator
+//     then holds 4 consecutive channels of one pixel in 4 consecutive registers;
+//   * activations: zero-padded 6 x 66 pixel halo tile of one 48-ci chunk in LDS, pixel stride 112 B
+//     (7 x 16 B, odd => conflict-free ds_read_b128), staged global -> registers -> LDS with every
+//     (thread, round)-dependent quantity precomputed as bit masks; chunk 1 is fetched into registers
+//     under the last tap of chunk 0, the next item's chunk 0 under the epilogue;
+//   * weights: one 9 KB slab per (tap, chunk) copied global -> LDS with global_load_lds (wave-uniform
+//     base + one per-lane offset) into a 3-deep ring, issued two phases ahead, so the fragments of the
+//     next phase's first step can be read before the barrier that ends the current phase;
+//   * fragments are double-buffered in registers and the five ds_reads of step s+1 sit one each in the
+//     gaps between the six MFMAs of step s (alone in a gap a ds_read_b128 is free; clustered they stall
+//     the wave ~30 cycles each, and a vector ALU instruction in the stream costs about as much:
+//     tools/issuebench.cpp);
+//   * epilogue, registers only: bias (accumulator start) -> PReLU -> (+ residual, prefetched before the
+//     last tap) -> bf16 pack + two v_permlane32_swap per 16-byte piece -> NHWC stores; optional
+//     per-tile channel sums for ChannelAttention's pool (fixed order => deterministic).
 #include "srgen_internal.h"
 
 #include <type_traits>
@@ -180,7 +185,27 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(Conv3x3Args a, int
     float* const ldsSlope = ldsBias + 4 * 96;
 
     const int tid16 = tid * 16;
+    // ---- A staging: halo tile of one ci chunk, global -> registers -> LDS ----------------------------
+    // Thread t moves the 16-byte unit q = t % 6 of pixel P = t/6 + 42*it of the 6 x 66 tile in round
+    // it = 0..9 (threads 252..255 idle).  Everything that depends on (t, it) only is formed ONCE, as bit
+    // masks over it: a vector ALU instruction inside the MFMA stream costs ~28 cycles, and the obvious
+    // form (divide the piece index by 6 and by 66, test both coordinates, per round and per item) was
+    // 7 % of the kernel.  Pixel P sits at row rb + wrap, column p0 + rem - 66*wrap with (rb, rem) =
+    // divmod(42*it, 66) compile-time and wrap = (p0 + rem >= 66) a per-lane bit.
     u32x4 stage[10];
+    const int p0 = tid / 6, q6 = tid - p0 * 6;
+    const int a_g0 = p0 * kC + q6 * 8;                    // element offset of the unit inside its row segment
+    char* const a_l0 = lds + p0 * PS + q6 * 16;           // LDS address of round 0 (round it: + it*42*PS)
+    unsigned a_wtb = 0, a_col = 0;       // bits it: wrap | 10+it: row 0 | 20+it: row 5;  it: unused | 10+it: col 0 | 20+it: col 65
+#pragma unroll
+    for (int it = 0; it < 10; ++it) {
+        const int rb = (42 * it) / HWP, rem = (42 * it) % HWP;
+        const bool wrap = p0 + rem >= HWP;
+        const int r = rb + (wrap ? 1 : 0), cc = p0 + rem - (wrap ? HWP : 0);
+        const bool used = tid < 252 && p0 + 42 * it < HH * HWP;
+        a_wtb |= (wrap ? 1u : 0u) << it | (r == 0 ? 1u : 0u) << (10 + it) | (r == HH - 1 ? 1u : 0u) << (20 + it);
+        a_col |= (used ? 0u : 1u) << it | (cc == 0 ? 1u : 0u) << (10 + it) | (cc == HWP - 1 ? 1u : 0u) << (20 + it);
+    }
     auto load_a = [&](const Item& t, int c) {
 #if defined(C3_NOMEM) && (C3_NOMEM & 1)      // development: always the same (L2-resident) tile
         const __bf16* in = (const __bf16*)a.in;
@@ -189,30 +214,29 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(Conv3x3Args a, int
         const __bf16* in = (const __bf16*)a.in + (size_t)t.n * HW * HW * kC;
         const int x0 = t.tx * TW, y0 = t.ty * TH;
 #endif
-        const int tv = opaque(tid);
+        // rounds whose pixel is outside the image (or unused): zero
+        unsigned bad = a_col;
+        if (x0 == 0) bad |= a_col >> 10;
+        if (x0 + TW == HW) bad |= a_col >> 20;
+        if (y0 == 0) bad |= a_wtb >> 10;
+        if (y0 + TH == HW) bad |= a_wtb >> 20;
+        const __bf16* base = in + ((ptrdiff_t)(y0 - 1) * HW + x0 - 1) * kC + c * CK;     // tile origin (may lie outside)
 #pragma unroll
         for (int it = 0; it < 10; ++it) {
-            const int i = tv + it * 256;
+            const int rb = (42 * it) / HWP, rem = (42 * it) % HWP;
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (i < A_ITEMS) {
-                const int pix = i / 6, q = i - pix * 6;
-                const int r = pix / HWP, cc = pix - r * HWP;
-                const int gy = y0 - 1 + r, gx = x0 - 1 + cc;
-                if ((unsigned)gy < (unsigned)HW && (unsigned)gx < (unsigned)HW)
-                    v = *(const u32x4*)(in + ((size_t)gy * HW + gx) * kC + c * CK + q * 8);
+            if (!((bad >> it) & 1u)) {
+                const int off = a_g0 + (int)((a_wtb >> it) & 1u) * ((HW - HWP) * kC);
+                v = *(const u32x4*)(base + (ptrdiff_t)(rb * HW + rem) * kC + off);
             }
             stage[it] = v;
         }
     };
     auto store_a = [&]() {
-        const int tv = opaque(tid);
+        if (tid < 252) {
 #pragma unroll
-        for (int it = 0; it < 10; ++it) {
-            const int i = tv + it * 256;
-            if (i < A_ITEMS) {
-                const int pix = i / 6, q = i - pix * 6;
-                *(u32x4*)(ldsA + pix * PS + q * 16) = stage[it];
-            }
+            for (int it = 0; it < 10; ++it)
+                if (it < 9 || p0 + 42 * 9 < HH * HWP) *(u32x4*)(a_l0 + it * 42 * PS) = stage[it];
         }
     };
     // async slab copy, 576 x 16 B, slab j = (tap j%9, chunk j/9) of cout block cb into ring
