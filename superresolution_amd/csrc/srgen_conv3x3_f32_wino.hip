@@ -301,6 +301,17 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f32_wino_kernel(Conv3x3Args a,
         // ---- main loop: nu > chunk > xi, one flat software pipeline -----------------------------
         // Invariant at the top of a chunk iteration: V holds this chunk's V, ua the U fragments of
         // its xi = 0, and this chunk's LDS buffers have landed (barrier of the previous chunk).
+        // The residual of the lane's 4 pixels (24 16-byte pieces): loaded in MFMA gaps of the first two
+        // chunks of the nu = 3 pass, one every second or third gap -- a wave load here touches 16 cache lines, and 24
+        // of them issued back to back stall the wave in the texture path for ~5k cycles.  Wave-uniform
+        // base + one per-lane offset + immediates: no address arithmetic between the MFMAs.
+        const int oy = cur.ty * 4 + 2 * tr, ox = cur.tx * 64 + 2 * tt;
+        f32x4 rr[RES ? 24 : 1];
+        const char* const rbase = (const char*)((const float*)a.res + (((size_t)cur.n * HW + cur.ty * 4) * HW + cur.tx * 64) * kC);
+        const unsigned roff = (unsigned)opaque(((2 * tr * HW + 2 * tt) * kC + 4 * kq) * 4);
+        auto load_res = [&](int q) {
+            rr[RES ? q : 0] = *(const f32x4*)(rbase + (q / 12) * (HW * kC * 4) + roff + (((q / 6) & 1) * kC + 16 * (q % 6)) * 4);
+        };
         auto run_nu = [&](auto NU) {
             constexpr int nu = decltype(NU)::value;
             constexpr int nu_next = (nu + 1) & 3;
@@ -309,8 +320,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f32_wino_kernel(Conv3x3Args a,
             for (int xi = 0; xi < 4; ++xi)
 #pragma unroll
                 for (int mt = 0; mt < 6; ++mt) M[xi][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-            for (int chunk = 0; chunk < 6; ++chunk) {
+            // (PEEL: the chunk is one of the two peeled ones of a residual conv's nu = 3 pass, which carry
+            // the residual loads -- as straight-line code, so that the loads are not inside a loop, where
+            // the compiler would wait for each with vmcnt(0))
+            auto do_chunk = [&](const int chunk, auto PEEL) {
+                constexpr bool peel = decltype(PEEL)::value;
                 // chunk sequence number s = nu*6 + chunk lives in buffer s % 3 = chunk % 3; s + 1 is being
                 // read ahead at xi = 3, s + 2 is staged (this nu's, the next nu's, or the next item's: nx is
                 // this item again after the last one, a harmless re-stage that keeps the vmcnt arithmetic)
@@ -344,9 +358,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f32_wino_kernel(Conv3x3Args a,
                         // issued for s+2 during this chunk stay in flight (vmcnt counts in order) -- and
                         // for this wave's LDS reads of the buffer that s+3 will overwrite.
                         asm volatile("" ::: "memory");
-                        // (the first barrier of nu = 3 also leaves the 24 residual loads in flight, which
-                        // were issued just before this chunk's staging: vmcnt(36))
-                        if (RES && nu == 3 && chunk == 0) __builtin_amdgcn_s_waitcnt(0x8074);
+                        // Residual convs, nu = 3: the loads issued behind the last cluster of chunks 0 and 1 stay
+                        // in flight too -- chunk 0: 12 + 6, chunk 1: 12 + 12 + 6, chunk 2: 12 + 12.
+                        if (peel) {
+                            if (chunk == 0) __builtin_amdgcn_s_waitcnt(0x4072);               // vmcnt(18)
+                            else __builtin_amdgcn_s_waitcnt(0x407e);                          // vmcnt(30)
+                        } else if (RES && nu == 3 && chunk == 2) __builtin_amdgcn_s_waitcnt(0x4078);          // vmcnt(24)
                         else __builtin_amdgcn_s_waitcnt(0x0070 | 12);     // vmcnt(12) lgkmcnt(0)
                         __builtin_amdgcn_s_barrier();
                         asm volatile("" ::: "memory");
@@ -354,7 +371,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f32_wino_kernel(Conv3x3Args a,
                     __builtin_amdgcn_sched_barrier(0);
                     const UF& u = (xi & 1) ? ub : ua;
                     UF& un = (xi & 1) ? ua : ub;
-                    // 24 MFMAs with ONE LDS read in every fourth gap: there a ds_read_b128 issues for
+                    // 24 MFMAs with ONE LDS read in every third gap: there a ds_read_b128 issues for
                     // free, in a cluster in front of the block each costs ~30 cycles of an idle matrix
                     // pipe (tools/issuebench.cpp).  xi 0..2: the U fragments of xi+1; xi 3: the raw halo
                     // reads and the first U fragments of the next chunk.
@@ -363,9 +380,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f32_wino_kernel(Conv3x3Args a,
                         const int e = sl / 6, mt = sl % 6;
                         mfma_acc(M[xi][mt], u.u[mt][e], V[xi][e]);
                         if (xi < 3) {
-                            if (sl % 4 == 1) un.u[sl / 4] = *(const f32x4*)(lds + ua_cur + ((xi + 1) * 4 * 96 + 16 * (sl / 4)) * 16);
+                            // (with LDS-DMA in the loop the compiler waits for ALL outstanding LDS reads at the
+                            // next block's first MFMA: the last read is issued 7 gaps before that)
+                            if (sl % 3 == 1 && sl / 3 < 6) un.u[sl / 3] = *(const f32x4*)(lds + ua_cur + ((xi + 1) * 4 * 96 + 16 * (sl / 3)) * 16);
                             // descriptors of the next cluster (scalar work, free in these gaps)
                             if (xi < 2 && sl % 6 == 2) make_desc(st, 4 * (xi + 1) + sl / 6, sl / 6);
+                            // residual pieces: AFTER the chunk's last staging cluster, so that (vmcnt counts in
+                            // order) no barrier forces them home for the next two chunks
+                            if (peel && xi == 2 && sl % 3 == 0 && sl != 12 && sl < 21) load_res(chunk * 12 + (sl < 12 ? sl / 3 : sl / 3 - 1));
                             if (xi == 2 && sl == 2) {
                                 // the next chunk iteration stages ITS s+2 into the buffer this one is reading
                                 if (chunk < 3) st = make_stage(cur, nu, chunk + 3, buf);
@@ -375,6 +397,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f32_wino_kernel(Conv3x3Args a,
                             if (xi == 2 && sl >= 8 && sl % 4 == 0 && sl / 4 - 2 < 4) make_desc(st, sl / 4 - 2, sl / 4 - 2);
                         } else {
                             if (sl < 16 && sl % 2 == 1) R[sl / 2] = *(const f32x4*)(lds + va[sl / 2]);
+                            if (peel && sl < 12 && sl % 2 == 0) load_res(chunk * 12 + 6 + sl / 2);
                             if (sl >= 16 && sl < 22) ua.u[sl - 16] = *(const f32x4*)(lds + ua_nxt + 16 * (sl - 16) * 16);
                         }
                         __builtin_amdgcn_sched_barrier(0);
@@ -384,6 +407,15 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f32_wino_kernel(Conv3x3Args a,
                         else combine(V, R, nu_next);
                     }
                 }
+            };
+            if (RES && nu == 3) {
+                do_chunk(0, std::true_type{});
+                do_chunk(1, std::true_type{});
+#pragma unroll 1
+                for (int chunk = 2; chunk < 6; ++chunk) do_chunk(chunk, std::false_type{});
+            } else {
+#pragma unroll 1
+                for (int chunk = 0; chunk < 6; ++chunk) do_chunk(chunk, std::false_type{});
             }
             // the asm MFMAs are opaque to the hazard recognizer: let the last ones retire before M is read
             asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
@@ -416,14 +448,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f32_wino_kernel(Conv3x3Args a,
         run_nu(std::integral_constant<int, 0>{});
         run_nu(std::integral_constant<int, 1>{});
         run_nu(std::integral_constant<int, 2>{});
-        // the residual of the lane's 4 pixels: in flight under the whole nu = 3 pass
-        const int oy = cur.ty * 4 + 2 * tr, ox = cur.tx * 64 + 2 * tt;
-        f32x4 rr[RES ? 24 : 1];
-        if (RES) {
-#pragma unroll
-            for (int q = 0; q < 24; ++q)
-                rr[RES ? q : 0] = *(const f32x4*)((const float*)a.res + (((size_t)cur.n * HW + oy + q / 12) * HW + ox + ((q / 6) & 1)) * kC + 4 * kq + 16 * (q % 6));
-        }
         run_nu(std::integral_constant<int, 3>{});
 
         // ---- epilogue: PReLU -> (+ residual) -> 16-byte NHWC stores ------------------------------
