@@ -51,6 +51,18 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base)
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// The weight-slab copies go through inline asm: with an LDS-DMA instruction it can see inside a loop the
+// compiler's wait-count pass waits lgkmcnt(0) before every use of an LDS read there, i.e. each k16-step
+// would start by waiting for the fragment read issued one MFMA earlier.  Hidden from it, the copies are
+// waited for explicitly (vmcnt(0) in front of every barrier that publishes a slab), and the fragment
+// reads get counted waits.  sbase: wave-uniform; lds_addr: LDS byte address of the wave's 1 KB piece.
+__device__ __forceinline__ void glds16_raw(const void* sbase, unsigned voff, unsigned lds_addr)
+{
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :: "v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
+}
+__device__ __forceinline__ void wait_vm0() { __builtin_amdgcn_s_waitcnt(0x0F70); }      // vmcnt(0) only
+
 __device__ __forceinline__ float bf16_lo(unsigned v) { return __uint_as_float(v << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned v) { return __uint_as_float(v & 0xffff0000u); }
 __device__ __forceinline__ unsigned pack_bf16(float lo, float hi)
@@ -185,6 +197,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(Conv3x3Args a, int
     float* const ldsSlope = ldsBias + 4 * 96;
 
     const int tid16 = tid * 16;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
     // ---- A staging: halo tile of one ci chunk, global -> registers -> LDS ----------------------------
     // Thread t moves the 16-byte unit q = t % 6 of pixel P = t/6 + 42*it of the 6 x 66 tile in round
     // it = 0..9 (threads 252..255 idle).  Everything that depends on (t, it) only is formed ONCE, as bit
@@ -244,13 +257,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(Conv3x3Args a, int
     auto load_b = [&](int cb, int j) {
         const int tap = j % 9, c = j / 9;
         const char* src = (const char*)a.wpack + ((size_t)((cb * 9 + tap) * 12 + 6 * c) * 96) * 16;
-        char* dst = ldsB + (j % NRING) * SLAB;
+        const unsigned dst = lds_base + A_BYTES + (j % NRING) * SLAB + w * 1024;
         // wave-uniform base + one per-lane 32-bit offset: global_load_lds v_off, s[base] with no vector
         // address arithmetic in the MFMA stream (a VALU instruction between MFMAs costs ~28 cycles);
         // the 64-unit tail of the slab is wave 0's alone (a scalar branch) instead of 16 lanes of each wave
-        glds16(src + (unsigned)opaque(tid16), dst + w * 1024);
-        glds16(src + 4096 + (unsigned)opaque(tid16), dst + 4096 + w * 1024);
-        if (w == 0) glds16(src + 8192 + (unsigned)opaque(tid16), dst + 8192);
+        glds16_raw(src, (unsigned)tid16, dst);
+        glds16_raw(src + 4096, (unsigned)tid16, dst + 4096);
+        if (w == 0) glds16_raw(src + 8192, (unsigned)tid16, dst + 8192);
     };
     // Residual of this lane's outputs: pixel (y0 + w, x0 + 32*mt + p); per accumulator tile
     // (mt, nt) two 16-byte pieces P = 0, 1 at channels 32*nt + 16*P + 8*h (see the epilogue).
@@ -285,6 +298,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(Conv3x3Args a, int
         for (int i = 0; i < C3_STAG; ++i) __builtin_amdgcn_s_sleep(100);
     }
     store_a();
+    wait_vm0();                                   // slabs 0, 1 (asm copies: not known to the compiler)
     __syncthreads();
 
     Frags f0, f1;
@@ -352,7 +366,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(Conv3x3Args a, int
                 __builtin_amdgcn_sched_barrier(0);
                 if (s & 1) mma_step(acc, f1); else mma_step(acc, f0);
 #endif
-                if (g == 2) __syncthreads();       // slabs j+1, j+2 landed; slab j is free
+                if (g == 2) {                      // slabs j+1, j+2 landed; slab j is free
+                    asm volatile("" ::: "memory");
+                    wait_vm0();
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                }
             }
         };
 #ifdef C3_PRIO
@@ -470,6 +489,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(Conv3x3Args a, int
         C3_STAMP(5);
         if (!has_next) break;
         store_a();
+        wait_vm0();
         __syncthreads();                          // next A chunk 0 and its slabs 0, 1 are in LDS
         item = nxt;
         cur = nx;
