@@ -19,6 +19,9 @@ Extra objects on that line:
                 bf16 dense (MI355X_MICROARCH.md); traffic = HBM bytes per launch from the committed
                 rocprofv3 PMC summary (profiles/traffic_<dtype>.json, tools/summarize_profiles.py:
                 FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate --pmc passes).
+  psnr          the "PSNR delta vs reference" half of BASELINE.json's metric: utils.psnr semantics
+                (srgen_metrics) against a synthetic target; for bf16 the delta to this library's fp32 path,
+                which the golden fixtures pin to the reference (bar 0.05 dB).
   cpu_baseline  the reference's forward restated with stock torch CPU ops (oracle/torch_ref.py,
                 kind "port": same ATen conv kernels the reference dispatches) on the box's host
                 cores, batch 16, bounded to ~10-20 s.
@@ -151,6 +154,24 @@ def main():
             roof["note"] = ("Winograd F(2x2,3x3): achieved/frac count the conv's algorithmic FLOPs (SURVEY 8d); "
                             "the kernel executes 4/9 of them on the matrix pipe (mfma_executed)")
 
+    # ---- PSNR delta (the second half of BASELINE.json's metric), outside the timed region ---------
+    # psnr(y, hr) per utils.psnr (srgen_metrics) against a synthetic target; for bf16 the delta to the fp32
+    # path of this library on the same weights and inputs (the fp32 path itself is pinned to the
+    # reference's output by the golden fixtures: tests/test_gpu_generator.py, <= 1e-4, measured 2e-6).
+    psnr = None
+    if rank == 0:
+        from superresolution_amd.functional import batch_metrics
+        hr = torch.rand((args.batch, 3, 125, 125), generator=torch.Generator(device="cpu").manual_seed(1)).to(dev)
+        y32 = g(x.float()).clamp(0, 1)
+        p32 = float(batch_metrics(y32, hr)[0])
+        psnr = {"psnr_fp32_path_db": round(p32, 4)}
+        if args.dtype == "bf16":
+            yb = y.float().clamp(0, 1)
+            pb = float(batch_metrics(yb, hr)[0])
+            psnr.update({"psnr_bf16_path_db": round(pb, 4), "psnr_delta_db": round(pb - p32, 5),
+                         "psnr_bf16_vs_fp32_output_db": round(float(batch_metrics(yb, y32)[0]), 2),
+                         "bar": "|delta| <= 0.05 dB (BASELINE.json north_star)"})
+
     # ---- HBM-bound kernels of the path: achieved GB/s against the 8 TB/s HBM3E peak ------------
     hbm = {}
     if rank == 0:
@@ -193,7 +214,7 @@ def main():
                        "parallelism": f"batch-sharded x{world}, weights replicated"},
             "end_to_end_tflops": round(value * FLOP_PER_IMAGE / 1e12, 2),
             "end_to_end_frac_of_peak": round(value / world * FLOP_PER_IMAGE / 1e12 / PEAK[args.dtype], 4),
-            "roofline": roof, "kernels": kernels, "hbm_kernels": hbm,
+            "roofline": roof, "kernels": kernels, "hbm_kernels": hbm, "psnr": psnr,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
