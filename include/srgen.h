@@ -144,6 +144,51 @@ SRGEN_API int srgen_metrics_scratch_bytes(int n, int c, int hgt, int wid, size_t
 SRGEN_API int srgen_metrics(const float* sr, const float* hr, int n, int c, int hgt, int wid,
                   float* out3, void* scratch, size_t scratch_bytes, void* stream);
 
+/* ---- Discriminator + relativistic-average GAN loss (forward values) ------------------------
+ * SURVEY.md 8(f) "next" row 3: the PatchGAN critic the reference's GAN phase evaluates on hr and on
+ * generator output (train.py:145-176).  Same conventions as above; fp32 only.  These entry points
+ * compute forward VALUES: the backward pass of the reference's training step is not built. */
+typedef struct srdisc_handle srdisc_handle;
+
+/* Discriminator(in_ch=3, base_ch=64) -- Discriminator.py:18.  This build has kernels for
+ * in_ch == 3, base_ch == 64; anything else -> SRGEN_E_UNSUPPORTED. */
+typedef struct srdisc_config {
+    int32_t in_ch;
+    int32_t base_ch;
+} srdisc_config;
+
+/* Replaces: Discriminator.__init__ + .to(device) (Discriminator.py:17-40, train.py:248,251). */
+SRGEN_API int srdisc_create(const srdisc_config* cfg, srdisc_handle** out);
+SRGEN_API int srdisc_destroy(srdisc_handle* h);
+
+/* Replaces: Module.load_state_dict for the discriminator.  The 20 reference keys
+ * ("backbone.0.weight", "backbone.2.block.0.bias", ..., "head.2.weight", "head.2.bias";
+ * Discriminator.py:22-38), fp32, contiguous, host memory.  srdisc_commit_weights packs them for
+ * the MFMA kernel and uploads them; missing keys -> SRGEN_E_KEY. */
+SRGEN_API int srdisc_set_tensor(srdisc_handle* h, const char* key, const float* host_data, size_t numel);
+SRGEN_API int srdisc_commit_weights(srdisc_handle* h, void* stream);
+
+/* Bytes of caller-provided device workspace (256-byte aligned) for n images of hgt x wid. */
+SRGEN_API int srdisc_workspace_bytes(const srdisc_handle* h, int n, int hgt, int wid, size_t* bytes);
+
+/* Replaces: Discriminator.forward (Discriminator.py:49-50; train.py:152-153,168-169).
+ *   x      : device, (n, 3, hgt, wid) NCHW contiguous fp32 (the reference feeds 125 x 125)
+ *   logits : device, (n, 1, oh, ow) fp32, oh = s(s(s(s(hgt)))), s(v) = (v - 1) / 2 + 1: the four
+ *            stride-2 convs (125 -> 63 -> 32 -> 16 -> 8)
+ *   taps   : NULL, or SRDISC_NUM_TAPS device pointers (NULL entries are skipped) receiving the
+ *            NCHW fp32 output of each of the ten convs after its LeakyReLU (parity tests). */
+#define SRDISC_NUM_TAPS 10
+SRGEN_API int srdisc_forward(srdisc_handle* h, const float* x, float* logits, void* workspace,
+                             size_t workspace_bytes, int n, int hgt, int wid, void* const* taps,
+                             void* stream);
+
+/* Replaces: RelativisticAverageLoss.discriminator_loss / .generator_loss (Discriminator.py:53-72):
+ * BCE-with-logits on real - mean(fake) and fake - mean(real), targets (real_label, fake_label) for
+ * the discriminator loss and (0, 1) for the generator loss.  real: n_real floats, fake: n_fake
+ * floats (device).  out2: device, {discriminator_loss, generator_loss}; stays on the device. */
+SRGEN_API int srgen_ragan_loss(const float* real, const float* fake, size_t n_real, size_t n_fake,
+                               float real_label, float fake_label, float* out2, void* stream);
+
 SRGEN_API const char* srgen_last_error(void);
 SRGEN_API int srgen_abi_version(void);
 

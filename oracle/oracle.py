@@ -234,3 +234,47 @@ def generator_forward(sd: Dict[str, np.ndarray], x, taps: Optional[dict] = None,
     o = conv2d(o, sd["output.2.weight"], sd["output.2.bias"])
     tap("output2_full", o)
     return crop(o, 125, 125)                                         # :80
+
+
+# ---- composition: Discriminator.forward, Discriminator.py:17-50 -----------------------
+
+DISC_LAYERS = (("backbone.0", 1), ("backbone.2.block.0", 2), ("backbone.3.block.0", 1),
+               ("backbone.4.block.0", 2), ("backbone.5.block.0", 1), ("backbone.6.block.0", 2),
+               ("backbone.7.block.0", 1), ("backbone.8.block.0", 2), ("head.0", 1), ("head.2", 1))
+
+
+def leaky_relu(x, slope=0.2) -> np.ndarray:
+    """nn.LeakyReLU(0.2) -- Discriminator.py:10,24,36."""
+    x = _f32(x)
+    return np.where(x > 0, x, x * np.float32(slope)).astype(np.float32)
+
+
+def discriminator_forward(sd: Dict[str, np.ndarray], x, taps: Optional[list] = None) -> np.ndarray:
+    """fp32 forward of the reference Discriminator from a numpy state_dict (20 keys).
+
+    A 3x3 / pad 1 / stride 2 conv (Discriminator.py:9) is the stride-1 conv sampled at even output
+    positions, so the strided layers run oracle_conv2d and keep [::2, ::2].  ``taps`` (optional
+    list) receives the ten post-activation conv outputs."""
+    cur = _f32(x)
+    for i, (key, stride) in enumerate(DISC_LAYERS):
+        cur = conv2d(cur, sd[key + ".weight"], sd[key + ".bias"])
+        if stride == 2:
+            cur = np.ascontiguousarray(cur[:, :, ::2, ::2])
+        if i != len(DISC_LAYERS) - 1:                       # no activation after head.2 (:37)
+            cur = leaky_relu(cur, 0.2)
+        if taps is not None:
+            taps.append(cur)
+    return cur
+
+
+def ragan_losses(real, fake, real_label=0.9, fake_label=0.1):
+    """(discriminator_loss, generator_loss) of RelativisticAverageLoss -- Discriminator.py:53-72,
+    in fp64.  BCEWithLogits(x, t) = mean(max(x,0) - x*t + log1p(exp(-|x|)))."""
+    r, f = np.asarray(real, np.float64).ravel(), np.asarray(fake, np.float64).ravel()
+
+    def bce(x, t):
+        return float(np.mean(np.maximum(x, 0) - x * t + np.log1p(np.exp(-np.abs(x)))))
+
+    rf, fr = r - f.mean(), f - r.mean()                     # :61-62, :68-69
+    return ((bce(rf, real_label) + bce(fr, fake_label)) / 2,      # :63-65
+            (bce(rf, 0.0) + bce(fr, 1.0)) / 2)                    # :70-72

@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(CSRC, "libsrgen.so")
 
 SRGEN_F32, SRGEN_BF16 = 0, 1
 NUM_TAPS = 11
+DISC_NUM_TAPS = 10
 TAP_NAMES = ("stem", "block0", "block7", "ca8", "block16", "ca17", "skip", "upsample", "output1",
              "ca8_scale", "ca17_scale")
 
@@ -26,6 +27,10 @@ class SrgenError(RuntimeError):
 
 class srgen_config(ctypes.Structure):
     _fields_ = [("num_blocks", ctypes.c_int32), ("in_ch", ctypes.c_int32), ("base_ch", ctypes.c_int32)]
+
+
+class srdisc_config(ctypes.Structure):
+    _fields_ = [("in_ch", ctypes.c_int32), ("base_ch", ctypes.c_int32)]
 
 
 def build(force: bool = False, jobs: int = 4) -> str:
@@ -63,6 +68,16 @@ def lib() -> ctypes.CDLL:
     L.srgen_normalize.argtypes = [vp, vp, sz, ctypes.c_float, i, vp]
     L.srgen_metrics_scratch_bytes.argtypes = [i, i, i, i, ctypes.POINTER(sz)]
     L.srgen_metrics.argtypes = [vp, vp, i, i, i, i, vp, vp, sz, vp]
+    L.srdisc_create.argtypes = [ctypes.POINTER(srdisc_config), ctypes.POINTER(vp)]
+    L.srdisc_destroy.argtypes = [vp]
+    L.srdisc_set_tensor.argtypes = [vp, ctypes.c_char_p, vp, sz]
+    L.srdisc_commit_weights.argtypes = [vp, vp]
+    L.srdisc_workspace_bytes.argtypes = [vp, i, i, i, ctypes.POINTER(sz)]
+    L.srdisc_forward.argtypes = [vp, vp, vp, vp, sz, i, i, i, ctypes.POINTER(vp), vp]
+    L.srgen_ragan_loss.argtypes = [vp, vp, sz, sz, ctypes.c_float, ctypes.c_float, vp, vp]
+    for name in ("srdisc_create", "srdisc_destroy", "srdisc_set_tensor", "srdisc_commit_weights",
+                 "srdisc_workspace_bytes", "srdisc_forward", "srgen_ragan_loss"):
+        getattr(L, name).restype = i
     for name in ("srgen_create", "srgen_destroy", "srgen_set_tensor", "srgen_commit_weights",
                  "srgen_workspace_bytes", "srgen_forward", "srgen_forward_taps", "srgen_forward_profile", "srgen_bilinear_resize", "srgen_normalize",
                  "srgen_metrics_scratch_bytes", "srgen_metrics"):
@@ -73,11 +88,11 @@ def lib() -> ctypes.CDLL:
     return L
 
 
-def check(rc: int) -> None:
+def check(rc: int, module: str = "Generator") -> None:
     """Map a negative srgen return code to a Python exception carrying srgen_last_error()."""
     if rc == 0:
         return
     msg = lib().srgen_last_error().decode("utf-8", "replace")
     if rc == -2:                       # SRGEN_E_KEY: same exception type load_state_dict raises
-        raise RuntimeError(f"Error(s) in loading state_dict for Generator: {msg}")
+        raise RuntimeError(f"Error(s) in loading state_dict for {module}: {msg}")
     raise SrgenError(f"libsrgen error {rc}: {msg}")

@@ -1,0 +1,292 @@
+// srdisc_kernels.hip -- gfx950 kernels of the PatchGAN discriminator forward
+// (/root/reference/Discriminator.py:17-50) and the relativistic-average loss (:53-72).
+//
+// Activations between layers are NHWC fp32.  Every conv is 3x3, pad 1 (Discriminator.py:9,23,35,37):
+//   disc_stem_kernel   3 -> 64, stride 1: VALU, weights through scalar loads (K = 27 is too thin for
+//                      MFMA tiles); reads the caller's NCHW input, writes NHWC.
+//   disc_conv_kernel   Cin -> Cout, stride 1 or 2: implicit GEMM on v_mfma_f32_16x16x4_f32.
+//                      A = weights (rows = 16 output channels), B = activations (columns = 16 output
+//                      pixels), so a lane ends up with 4 consecutive channels of one pixel per
+//                      accumulator and, through the channel permutation of the weight pack, 16
+//                      consecutive channels over its four accumulators: 64-byte contiguous NHWC
+//                      stores.  A lane's B fragment for four k-steps is ONE 16-byte load (4 consecutive
+//                      input channels of its pixel), its A fragment one 16-byte load of the pack; no
+//                      LDS: the four waves of a workgroup share the weight fragments through L1.
+//   disc_tail_kernel   Cin -> 1: one wave per output pixel, lanes over input channels.
+//   ragan_loss_kernel  both losses of RelativisticAverageLoss in one single-workgroup launch.
+#include "srgen_internal.h"
+
+namespace srgen {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
+
+// ---- stem -------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void disc_stem_kernel(DiscStemArgs a, int total)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= total) return;
+    const int hw = a.H * a.W;
+    const int img = p / hw, r = p - img * hw;
+    const int y = r / a.W, x = r - y * a.W;
+    float in[27];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int iy = y + ky - 1, ix = x + kx - 1;
+            const bool v = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            const size_t off = v ? ((size_t)img * 3 * a.H + iy) * a.W + ix : 0;
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci) {
+                const float t = a.x[off + (v ? (size_t)ci * hw : 0)];
+                in[(ky * 3 + kx) * 3 + ci] = v ? t : 0.f;
+            }
+        }
+    float* o = a.out + (size_t)p * 64;
+#pragma unroll 1
+    for (int cg = 0; cg < 4; ++cg) {
+        float acc[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) acc[c] = a.bias[cg * 16 + c];
+#pragma unroll
+        for (int k = 0; k < 27; ++k)
+#pragma unroll
+            for (int c = 0; c < 16; ++c) acc[c] = fmaf(in[k], a.w[k * 64 + cg * 16 + c], acc[c]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 v = {lrelu(acc[4 * q], a.slope), lrelu(acc[4 * q + 1], a.slope),
+                       lrelu(acc[4 * q + 2], a.slope), lrelu(acc[4 * q + 3], a.slope)};
+            *reinterpret_cast<f32x4*>(o + cg * 16 + 4 * q) = v;
+        }
+    }
+}
+
+// ---- Cin -> Cout implicit GEMM ------------------------------------------------------------------
+// workgroup = 4 waves = 128 output pixels x 64 output channels; wave = 32 pixels (two 16-pixel
+// column groups) x 64 channels (four 16-row tiles) = 8 accumulators.  k runs over (tap, 16-channel
+// chunk); per chunk a lane loads 2 activation and 4 weight float4s for 32 MFMAs, the next chunk's
+// loads issued before the current chunk's MFMAs.
+struct Frag {
+    f32x4 x[2];
+    f32x4 w[4];
+};
+
+template <int STRIDE>
+__global__ __launch_bounds__(256, 2) void disc_conv_kernel(DiscConvArgs a, int OH, int OW, int M, int lg_nch)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int l16 = lane & 15, kq = lane >> 4;
+    const int ncb = a.Cout >> 6;
+    const int cb = blockIdx.x % ncb;
+    const int tile = blockIdx.x / ncb;
+    const int nch = 1 << lg_nch;
+    const int total = 9 * nch;
+
+    int p[2], img[2], oy[2], ox[2];
+    bool pv[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        p[g] = tile * 128 + wv * 32 + g * 16 + l16;
+        pv[g] = p[g] < M;
+        const int pc = pv[g] ? p[g] : 0;
+        img[g] = pc / (OH * OW);
+        const int r = pc - img[g] * (OH * OW);
+        oy[g] = r / OW;
+        ox[g] = r - oy[g] * OW;
+    }
+    const f32x4* wp = reinterpret_cast<const f32x4*>(a.wpack) + (size_t)cb * total * 256 + lane;
+
+    auto load = [&](Frag& f, int it) {
+        const int tap = it >> lg_nch, ch = it & (nch - 1);
+        const int ky = tap / 3, kx = tap - 3 * ky;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int iy = oy[g] * STRIDE + ky - 1, ix = ox[g] * STRIDE + kx - 1;
+            const bool v = pv[g] && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            const size_t off = v ? (((size_t)img[g] * a.H + iy) * a.W + ix) * a.Cin + ch * 16 + kq * 4 : 0;
+            const f32x4 t = *reinterpret_cast<const f32x4*>(a.in + off);
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            f.x[g] = v ? t : z;
+        }
+        const f32x4* w = wp + (size_t)it * 256;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) f.w[s] = w[s * 64];
+    };
+
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) acc[s][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto mma = [&](const Frag& f) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+                    acc[s][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.w[s][j], f.x[g][j], acc[s][g], 0, 0, 0);
+    };
+
+    Frag f0, f1;
+    load(f0, 0);
+    // total = 9 * nch is odd only for nch == 1, which the launcher does not allow (Cin >= 32)
+    for (int it = 0; it < total; it += 2) {
+        load(f1, it + 1);
+        mma(f0);
+        if (it + 2 < total) load(f0, it + 2);
+        mma(f1);
+    }
+
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        if (!pv[g]) continue;
+        float* o = a.out + (size_t)p[g] * a.Cout + cb * 64 + kq * 16;
+        const float* b = a.bias + cb * 64 + kq * 16;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(b + s * 4);
+            f32x4 r = acc[s][g] + bv;
+            r = f32x4{lrelu(r[0], a.slope), lrelu(r[1], a.slope), lrelu(r[2], a.slope), lrelu(r[3], a.slope)};
+            *reinterpret_cast<f32x4*>(o + s * 4) = r;
+        }
+    }
+}
+
+// ---- Cin -> 1 tail ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void disc_tail_kernel(DiscTailArgs a, int total)
+{
+    const int lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= total) return;                                  // wave-uniform
+    const int hw = a.H * a.W;
+    const int img = p / hw, r = p - img * hw;
+    const int y = r / a.W, x = r - y * a.W;
+    float sum = 0.f;
+    for (int tap = 0; tap < 9; ++tap) {
+        const int ky = tap / 3, kx = tap - 3 * ky;
+        const int iy = y + ky - 1, ix = x + kx - 1;
+        if (iy < 0 || iy >= a.H || ix < 0 || ix >= a.W) continue;
+        const float* src = a.in + (((size_t)img * a.H + iy) * a.W + ix) * a.Cin;
+        const float* w = a.w + (size_t)tap * a.Cin;
+        for (int c = lane * 4; c < a.Cin; c += 256) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(src + c);
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(w + c);
+            sum = fmaf(xv[0], wv[0], sum);
+            sum = fmaf(xv[1], wv[1], sum);
+            sum = fmaf(xv[2], wv[2], sum);
+            sum = fmaf(xv[3], wv[3], sum);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+    if (lane == 0) a.y[p] = sum + a.bias[0];
+}
+
+// ---- relativistic-average loss ---------------------------------------------------------------------
+// nn.BCEWithLogitsLoss()(x, t) per element: max(x, 0) - x*t + log1p(exp(-|x|))
+__device__ __forceinline__ float bce_logits(float x, float t)
+{
+    return fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
+}
+
+template <int N>
+__device__ void block_sum(double (&v)[N], double (*red)[N])
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v[i] += __shfl_xor(v[i], off);
+    __syncthreads();                                         // red may still be read from the last use
+    if (lane == 0)
+        for (int i = 0; i < N; ++i) red[wv][i] = v[i];
+    __syncthreads();
+    for (int i = 0; i < N; ++i) {
+        double t = 0.0;
+        for (int w = 0; w < nw; ++w) t += red[w][i];
+        v[i] = t;
+    }
+}
+
+__global__ __launch_bounds__(1024) void ragan_loss_kernel(const float* __restrict__ real,
+                                                          const float* __restrict__ fake, size_t nr, size_t nf,
+                                                          float real_label, float fake_label, float* out2)
+{
+    __shared__ double red[16][4];
+    double m[4] = {0.0, 0.0, 0.0, 0.0};
+    for (size_t i = threadIdx.x; i < nr; i += blockDim.x) m[0] += (double)real[i];
+    for (size_t i = threadIdx.x; i < nf; i += blockDim.x) m[1] += (double)fake[i];
+    block_sum(m, red);
+    const float mr = (float)(m[0] / (double)nr), mf = (float)(m[1] / (double)nf);   // real.mean(), fake.mean()
+    double t[4] = {0.0, 0.0, 0.0, 0.0};
+    for (size_t i = threadIdx.x; i < nr; i += blockDim.x) {
+        const float x = real[i] - mf;                        // r_vs_f           Discriminator.py:61,68
+        t[0] += (double)bce_logits(x, real_label);           // :63
+        t[2] += (double)bce_logits(x, 0.f);                  // :70
+    }
+    for (size_t i = threadIdx.x; i < nf; i += blockDim.x) {
+        const float x = fake[i] - mr;                        // f_vs_r           :62,69
+        t[1] += (double)bce_logits(x, fake_label);           // :64
+        t[3] += (double)bce_logits(x, 1.f);                  // :71
+    }
+    block_sum(t, red);
+    if (threadIdx.x == 0) {
+        out2[0] = (float)((t[0] / (double)nr + t[1] / (double)nf) * 0.5);   // :65
+        out2[1] = (float)((t[2] / (double)nr + t[3] / (double)nf) * 0.5);   // :72
+    }
+}
+
+}  // namespace
+
+hipError_t launch_disc_stem(const DiscStemArgs& a, hipStream_t s)
+{
+    const long long total = (long long)a.N * a.H * a.W;
+    if (total <= 0) return hipSuccess;
+    if (total > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(disc_stem_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a, (int)total);
+    return hipGetLastError();
+}
+
+hipError_t launch_disc_conv(const DiscConvArgs& a, hipStream_t s)
+{
+    if (a.N <= 0) return hipSuccess;
+    const int nch = a.Cin >> 4;
+    if (a.Cin % 32 || a.Cout % 64 || (nch & (nch - 1)) || (a.stride != 1 && a.stride != 2) || a.H < 1 || a.W < 1)
+        return hipErrorInvalidValue;
+    int lg = 0;
+    while ((1 << lg) < nch) ++lg;
+    const int OH = (a.H - 1) / a.stride + 1, OW = (a.W - 1) / a.stride + 1;
+    const long long M = (long long)a.N * OH * OW;
+    const long long blocks = ((M + 127) / 128) * (a.Cout >> 6);
+    if (M > 0x7fffffffLL || blocks > 0x7fffffffLL || (long long)a.N * a.H * a.W > 0x7fffffffLL)
+        return hipErrorInvalidValue;
+    if (a.stride == 1)
+        hipLaunchKernelGGL(disc_conv_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, a, OH, OW, (int)M, lg);
+    else
+        hipLaunchKernelGGL(disc_conv_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, a, OH, OW, (int)M, lg);
+    return hipGetLastError();
+}
+
+hipError_t launch_disc_tail(const DiscTailArgs& a, hipStream_t s)
+{
+    const long long total = (long long)a.N * a.H * a.W;
+    if (total <= 0) return hipSuccess;
+    if (total > 0x7fffffffLL || a.Cin % 4) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(disc_tail_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, s, a, (int)total);
+    return hipGetLastError();
+}
+
+hipError_t launch_ragan_loss(const float* real, const float* fake, size_t n_real, size_t n_fake,
+                             float real_label, float fake_label, float* out2, hipStream_t s)
+{
+    hipLaunchKernelGGL(ragan_loss_kernel, dim3(1), dim3(1024), 0, s, real, fake, n_real, n_fake, real_label,
+                       fake_label, out2);
+    return hipGetLastError();
+}
+
+}  // namespace srgen

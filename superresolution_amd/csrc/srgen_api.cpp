@@ -22,9 +22,10 @@
 using namespace srgen;
 
 namespace {
-
 thread_local char g_err[512] = "";
+}
 
+namespace srgen {
 int fail(int code, const char* fmt, ...)
 {
     va_list ap;
@@ -33,6 +34,9 @@ int fail(int code, const char* fmt, ...)
     va_end(ap);
     return code;
 }
+}  // namespace srgen
+
+namespace {
 
 #define HIP_TRY(expr)                                                                      \
     do {                                                                                   \

@@ -7,6 +7,9 @@
 
 namespace srgen {
 
+// records the message srgen_last_error() returns (thread-local) and returns `code`
+int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+
 constexpr int kC = 96;          // trunk width (base_ch)
 constexpr int kLR = 64;         // low-res side
 constexpr int kHR = 128;        // after PixelShuffle(2)
@@ -88,6 +91,36 @@ hipError_t launch_normalize(const float* x, void* y, size_t numel, float hr_max,
 size_t metrics_scratch_bytes(int n, int c, int h, int w);
 hipError_t launch_metrics(const float* sr, const float* hr, int n, int c, int h, int w,
                           float* out3, void* scratch, hipStream_t s);
+
+// ---- discriminator (Discriminator.py:17-50): NHWC fp32 activations (srdisc_kernels.hip) ---------
+struct DiscStemArgs {          // conv 3 -> 64, stride 1, pad 1, + LeakyReLU
+    const float* x;            // (N,3,H,W) NCHW
+    float* out;                // (N,H,W,64) NHWC
+    const float* w;            // [k 27][co 64], k = (ky*3 + kx)*3 + ci
+    const float* bias;         // [64]
+    int N, H, W;
+    float slope;
+};
+struct DiscConvArgs {          // conv Cin -> Cout (Cin % 16 == 0, Cout % 64 == 0), stride 1|2, pad 1
+    const float* in;           // (N,H,W,Cin)
+    float* out;                // (N,OH,OW,Cout), OH = (H-1)/stride + 1
+    const float* wpack;        // float4 units [cout/64][tap 9][cin/16][s 4][lane 64], see pack_disc_conv
+    const float* bias;         // [Cout]
+    int N, H, W, Cin, Cout, stride;
+    float slope;               // LeakyReLU slope
+};
+struct DiscTailArgs {          // conv Cin -> 1, stride 1, pad 1, no activation
+    const float* in;           // (N,H,W,Cin), Cin % 4 == 0
+    float* y;                  // (N,1,H,W)
+    const float* w;            // [tap 9][Cin]
+    const float* bias;         // [1]
+    int N, H, W, Cin;
+};
+hipError_t launch_disc_stem(const DiscStemArgs& a, hipStream_t s);
+hipError_t launch_disc_conv(const DiscConvArgs& a, hipStream_t s);
+hipError_t launch_disc_tail(const DiscTailArgs& a, hipStream_t s);
+hipError_t launch_ragan_loss(const float* real, const float* fake, size_t n_real, size_t n_fake,
+                             float real_label, float fake_label, float* out2, hipStream_t s);
 
 // ---- packed-weight geometry shared by the packers (host) and the kernels ---------------
 // fp32 3x3: float4 units  [cout_block][tap 9][ci4 24][co 96] -> 4 consecutive ci

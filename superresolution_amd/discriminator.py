@@ -1,0 +1,227 @@
+"""Drop-in ``Discriminator`` and ``RelativisticAverageLoss`` (forward values) on gfx950 kernels.
+
+Mirrors ``/root/reference/Discriminator.py:5-72`` and its call sites in the GAN phase
+(``train.py:152-154,168-170``): same constructors, same module tree and therefore the same 20
+``state_dict`` keys, parameter shapes and initialisation (default ``nn.Conv2d`` init followed by
+``kaiming_normal_(a=0.2)`` in ``modules()`` order, so ``torch.manual_seed(s); Discriminator()``
+yields the reference's weights), ``discriminator(x)`` returning ``(N, 1, 8, 8)`` logits for
+``125 x 125`` inputs, and ``loss.discriminator_loss(real, fake)`` / ``loss.generator_loss(real, fake)``
+returning 0-dim tensors.
+
+Scope: forward VALUES.  The reference calls these under autograd; the backward pass is not built
+(SURVEY.md 8(f) row 3 lists it as future work), so a call with gradient recording enabled on inputs
+or parameters that require grad raises instead of silently returning a graph-less tensor.  Wrap calls
+in ``torch.no_grad()``.  No eager-PyTorch or CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+class DiscBlock(nn.Module):
+    # keys: block.0.{weight,bias}                                        (Discriminator.py:5-14)
+    def __init__(self, in_ch: int, out_ch: int, stride: int = 1):
+        super().__init__()
+        self.block = nn.Sequential(nn.Conv2d(in_ch, out_ch, 3, stride=stride, padding=1),
+                                   nn.LeakyReLU(0.2, inplace=True))
+
+    def forward(self, *a, **k):  # pragma: no cover - guard
+        raise RuntimeError("DiscBlock is a parameter container of the fused HIP Discriminator; call the "
+                           "Discriminator itself")
+
+
+def _no_autograd(what: str, *tensors) -> None:
+    if torch.is_grad_enabled() and any(t.requires_grad for t in tensors):
+        raise NotImplementedError(
+            f"{what}: only forward values are built (no backward kernels); call it under torch.no_grad(). "
+            "There is no eager fallback.")
+
+
+class Discriminator(nn.Module):
+    """PatchGAN critic 3xHxW -> 1x(H/16)x(W/16) logits (``Discriminator.py:17-50``), HIP-backed."""
+
+    def __init__(self, in_ch: int = 3, base_ch: int = 64):
+        super().__init__()
+        self.in_ch, self.base_ch = in_ch, base_ch
+        f = base_ch
+        self.backbone = nn.Sequential(
+            nn.Conv2d(in_ch, f, 3, padding=1), nn.LeakyReLU(0.2, inplace=True),
+            DiscBlock(f, f, stride=2), DiscBlock(f, f * 2),
+            DiscBlock(f * 2, f * 2, stride=2), DiscBlock(f * 2, f * 4),
+            DiscBlock(f * 4, f * 4, stride=2), DiscBlock(f * 4, f * 8),
+            DiscBlock(f * 8, f * 8, stride=2))
+        self.head = nn.Sequential(nn.Conv2d(f * 8, f * 4, 3, padding=1), nn.LeakyReLU(0.2, inplace=True),
+                                  nn.Conv2d(f * 4, 1, 3, padding=1))
+        self._init_weights()
+        self._handles: Dict[int, int] = {}
+        self._weights_sig: Dict[int, Tuple] = {}
+        self._workspace: Dict[int, torch.Tensor] = {}
+
+    def _init_weights(self) -> None:                                      # Discriminator.py:42-47
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, a=0.2, nonlinearity="leaky_relu")
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+
+    # ---- HIP handle / weights ----------------------------------------------------------
+    def _signature(self) -> Tuple:
+        return tuple((t.data_ptr(), t._version) for t in self.state_dict(keep_vars=True).values())
+
+    def _handle(self, idx: int) -> int:
+        L = _lib.lib()
+        if idx not in self._handles:
+            cfg = _lib.srdisc_config(self.in_ch, self.base_ch)
+            h = ctypes.c_void_p()
+            with torch.cuda.device(idx):
+                _lib.check(L.srdisc_create(ctypes.byref(cfg), ctypes.byref(h)), "Discriminator")
+            self._handles[idx] = h.value
+        h = self._handles[idx]
+        sig = self._signature()
+        if self._weights_sig.get(idx) != sig:
+            keep = []
+            for key, t in self.state_dict().items():
+                c = t.detach().to(device="cpu", dtype=torch.float32).contiguous()
+                keep.append(c)
+                _lib.check(L.srdisc_set_tensor(h, key.encode(), c.data_ptr(), c.numel()), "Discriminator")
+            with torch.cuda.device(idx):
+                _lib.check(L.srdisc_commit_weights(h, torch.cuda.current_stream(idx).cuda_stream), "Discriminator")
+            self._weights_sig[idx] = sig
+        return h
+
+    @staticmethod
+    def out_size(v: int) -> int:
+        """Side after the four stride-2 convs (3x3, pad 1): 125 -> 63 -> 32 -> 16 -> 8."""
+        for _ in range(4):
+            v = (v - 1) // 2 + 1
+        return v
+
+    # ---- forward -------------------------------------------------------------------------
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self._run(x, None)
+
+    def forward_taps(self, x: torch.Tensor):
+        """(logits, [NCHW fp32 output of each of the ten convs after its LeakyReLU]) for parity tests."""
+        taps: list = []
+        y = self._run(x, taps)
+        return y, taps
+
+    def _run(self, x: torch.Tensor, taps: Optional[list]) -> torch.Tensor:
+        if not isinstance(x, torch.Tensor) or x.dim() != 4:
+            raise RuntimeError(f"Expected 4D (N, {self.in_ch}, H, W) input, got {tuple(getattr(x, 'shape', ()))}")
+        if x.shape[1] != self.in_ch:
+            raise RuntimeError(f"Given groups=1, weight of size [{self.base_ch}, {self.in_ch}, 3, 3], expected "
+                               f"input{list(x.shape)} to have {self.in_ch} channels, but got {x.shape[1]} "
+                               "channels instead")
+        if not x.is_cuda:
+            raise RuntimeError("the HIP discriminator runs on a ROCm device only (input is on "
+                               f"{x.device}); there is no CPU fallback. Move the module and input to 'cuda'.")
+        p = self.backbone[0].weight
+        if p.device != x.device:
+            raise RuntimeError(f"Input type ({x.device}) and weight type ({p.device}) should be the same")
+        if x.dtype != torch.float32:
+            raise RuntimeError(f"unsupported input dtype {x.dtype}: the discriminator kernels are fp32")
+        _no_autograd("Discriminator.forward", x, *self.parameters())
+        xc = x.detach().contiguous()
+        n, _, hgt, wid = xc.shape
+        idx = xc.device.index
+        oh, ow = self.out_size(hgt), self.out_size(wid)
+        y = torch.empty((n, 1, oh, ow), dtype=torch.float32, device=xc.device)
+        if n == 0:
+            return y
+        h = self._handle(idx)
+        L = _lib.lib()
+        need = ctypes.c_size_t()
+        _lib.check(L.srdisc_workspace_bytes(h, n, hgt, wid, ctypes.byref(need)), "Discriminator")
+        ws = self._workspace.get(idx)
+        if ws is None or ws.numel() < need.value:
+            self._workspace.pop(idx, None)
+            ws = None
+            ws = torch.empty(need.value, dtype=torch.uint8, device=xc.device)
+            self._workspace[idx] = ws
+        arr = None
+        if taps is not None:
+            f, sh, sw = self.base_ch, [hgt], [wid]
+            for _ in range(4):
+                sh.append((sh[-1] - 1) // 2 + 1)
+                sw.append((sw[-1] - 1) // 2 + 1)
+            chans = [f, f, 2 * f, 2 * f, 4 * f, 4 * f, 8 * f, 8 * f, 4 * f, 1]
+            level = [0, 1, 1, 2, 2, 3, 3, 4, 4, 4]
+            taps.extend(torch.empty((n, c, sh[l], sw[l]), dtype=torch.float32, device=xc.device)
+                        for c, l in zip(chans, level))
+            arr = (ctypes.c_void_p * _lib.DISC_NUM_TAPS)(*[t.data_ptr() for t in taps])
+        with torch.cuda.device(idx):
+            stream = torch.cuda.current_stream(idx).cuda_stream
+            _lib.check(L.srdisc_forward(h, xc.data_ptr(), y.data_ptr(), ws.data_ptr(), ws.numel(), n, hgt, wid,
+                                        arr, stream), "Discriminator")
+        return y
+
+    # ---- module protocol -------------------------------------------------------------------
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self._weights_sig.clear()
+        self._workspace.clear()
+        return out
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_handles"], state["_weights_sig"], state["_workspace"] = {}, {}, {}
+        return state
+
+    def __del__(self):
+        try:
+            L = _lib.lib()
+            for h in self.__dict__.get("_handles", {}).values():
+                L.srdisc_destroy(h)
+        except Exception:
+            pass
+
+
+class RelativisticAverageLoss(nn.Module):
+    """``Discriminator.py:53-72``: BCE-with-logits on ``real - fake.mean()`` / ``fake - real.mean()``.
+
+    Both losses come out of one single-launch kernel (``srgen_ragan_loss``); each method returns its
+    0-dim fp32 tensor, left on the device (no host sync)."""
+
+    def __init__(self, real_label: float = 0.9, fake_label: float = 0.1):
+        super().__init__()
+        self.real_label = real_label
+        self.fake_label = fake_label
+
+    def _both(self, real: torch.Tensor, fake: torch.Tensor) -> torch.Tensor:
+        for nm, t in (("real", real), ("fake", fake)):
+            if not isinstance(t, torch.Tensor) or not t.is_cuda:
+                raise RuntimeError(f"RelativisticAverageLoss: `{nm}` must be a tensor on a ROCm device; there is "
+                                   "no CPU fallback")
+            if t.dtype != torch.float32:
+                raise RuntimeError(f"RelativisticAverageLoss: `{nm}` is {t.dtype}; the kernel is fp32")
+        if real.device != fake.device:
+            raise RuntimeError(f"real is on {real.device}, fake on {fake.device}")
+        _no_autograd("RelativisticAverageLoss", real, fake)
+        r, f = real.detach().contiguous(), fake.detach().contiguous()
+        out = torch.empty(2, dtype=torch.float32, device=r.device)
+        if r.numel() == 0 or f.numel() == 0:
+            return out.fill_(float("nan"))                  # mean of an empty tensor, as torch gives
+        idx = r.device.index
+        with torch.cuda.device(idx):
+            _lib.check(_lib.lib().srgen_ragan_loss(r.data_ptr(), f.data_ptr(), r.numel(), f.numel(),
+                                                   float(self.real_label), float(self.fake_label),
+                                                   out.data_ptr(), torch.cuda.current_stream(idx).cuda_stream))
+        return out
+
+    def discriminator_loss(self, real: torch.Tensor, fake: torch.Tensor) -> torch.Tensor:
+        return self._both(real, fake)[0]
+
+    def generator_loss(self, real: torch.Tensor, fake: torch.Tensor) -> torch.Tensor:
+        return self._both(real, fake)[1]
+
+    def both_losses(self, real: torch.Tensor, fake: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(discriminator_loss, generator_loss) from one launch (no counterpart in the reference)."""
+        o = self._both(real, fake)
+        return o[0], o[1]

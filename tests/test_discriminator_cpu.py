@@ -1,0 +1,101 @@
+"""CPU checks for the discriminator row: the oracle's restatement of
+Discriminator.forward / RelativisticAverageLoss against the fixture made from the real reference
+(tests/golden/discriminator.npz, see make_golden.py), and the host-side mirror's contract."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, max_rel
+
+
+@pytest.fixture(scope="module")
+def gd():
+    import os
+    return np.load(os.path.join(GOLDEN, "discriminator.npz"))
+
+
+@pytest.fixture(scope="module")
+def seeded_disc():
+    """torch.manual_seed(0); Discriminator() -- how make_golden.py built the reference module."""
+    from superresolution_amd import Discriminator
+    torch.manual_seed(0)
+    return Discriminator()
+
+
+def test_mirror_reproduces_reference_keys_and_default_init(gd, seeded_disc):
+    sd = seeded_disc.state_dict()
+    assert list(sd.keys()) == [str(k) for k in gd["keys"]]
+    assert sum(v.numel() for v in sd.values()) == int(gd["n_params"]) == 5867585
+    sums = np.array([v.double().sum().item() for v in sd.values()])
+    # same RNG stream, same construction and init order: bit-identical weights, so identical fp64 sums
+    assert np.abs(sums - gd["key_sums"]).max() <= 1e-9
+
+
+def test_oracle_forward_matches_reference_logits(gd, golden, seeded_disc):
+    from oracle import oracle as O
+    from superresolution_amd import weights as W
+    sd = {k: v.numpy() for k, v in seeded_disc.state_dict().items()}
+    hr = W.synthetic_hr_batch(2, seed=1)
+    sr = golden["y_dense_sparse"]
+    taps = []
+    dr = O.discriminator_forward(sd, hr, taps)
+    df = O.discriminator_forward(sd, sr)
+    assert dr.shape == tuple(gd["out_shape"]) == (2, 1, 8, 8)
+    assert [t.shape[1:] for t in taps] == [(64, 125, 125), (64, 63, 63), (128, 63, 63), (128, 32, 32),
+                                            (256, 32, 32), (256, 16, 16), (512, 16, 16), (512, 8, 8),
+                                            (256, 8, 8), (1, 8, 8)]
+    assert max_rel(dr, gd["d_real"]) <= 1e-5
+    assert max_rel(df, gd["d_fake"]) <= 1e-5
+
+
+def test_oracle_ragan_losses_match_reference(gd):
+    from oracle import oracle as O
+    ld, lg = O.ragan_losses(gd["d_real"], gd["d_fake"])
+    assert abs(ld - float(gd["loss_d"])) <= 1e-6
+    assert abs(lg - float(gd["loss_g"])) <= 1e-6
+
+
+def test_strided_conv_restatement_on_odd_and_even_sizes():
+    """The oracle's stride-2 = stride-1[::2, ::2] identity, checked against torch's own strided conv."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(0)
+    for h, w in ((7, 10), (8, 5), (1, 3)):
+        x = rng.standard_normal((2, 5, h, w)).astype(np.float32)
+        k = rng.standard_normal((6, 5, 3, 3)).astype(np.float32)
+        b = rng.standard_normal(6).astype(np.float32)
+        ref = torch.nn.functional.conv2d(torch.from_numpy(x).double(), torch.from_numpy(k).double(),
+                                         torch.from_numpy(b).double(), stride=2, padding=1).numpy()
+        got = O.conv2d(x, k, b)[:, :, ::2, ::2]
+        assert got.shape == ref.shape
+        assert max_rel(got, ref) <= 1e-6
+
+
+def test_discriminator_fails_loudly_off_gpu_and_under_autograd(seeded_disc):
+    from superresolution_amd import RelativisticAverageLoss
+    x = torch.zeros(1, 3, 125, 125)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        seeded_disc(x)
+    with pytest.raises(RuntimeError, match="channels"):
+        seeded_disc(torch.zeros(1, 4, 125, 125))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        RelativisticAverageLoss().discriminator_loss(torch.zeros(2, 1, 8, 8), torch.zeros(2, 1, 8, 8))
+    assert Discriminator_out_sizes() == [8, 4, 1, 1]
+
+
+def Discriminator_out_sizes():
+    from superresolution_amd import Discriminator
+    return [Discriminator.out_size(v) for v in (125, 64, 16, 1)]
+
+
+def test_discriminator_argument_errors_without_gpu():
+    import ctypes
+    from superresolution_amd import _lib
+    L = _lib.lib()
+    h = ctypes.c_void_p()
+    cfg = _lib.srdisc_config(3, 32)
+    assert L.srdisc_create(ctypes.byref(cfg), ctypes.byref(h)) == -6       # SRGEN_E_UNSUPPORTED
+    assert b"base_ch=64" in L.srgen_last_error()
+    assert L.srdisc_create(None, ctypes.byref(h)) == -1
+    assert L.srdisc_set_tensor(None, b"backbone.0.weight", None, 0) == -1
+    assert L.srdisc_forward(None, None, None, None, 0, 1, 125, 125, None, None) == -1
+    assert L.srgen_ragan_loss(None, None, 1, 1, 0.9, 0.1, None, None) == -1

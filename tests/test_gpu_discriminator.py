@@ -1,0 +1,124 @@
+"""GPU parity tests of the discriminator row: the HIP forward and the RaGAN loss
+kernel, through the C ABI, against the fixture made from the real reference and the on-box oracle.
+fp32 bar as for the generator: max error normalised by max|ref| <= 1e-4."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, max_rel
+
+pytestmark = pytest.mark.gpu
+
+FP32_TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def gd():
+    return np.load(os.path.join(GOLDEN, "discriminator.npz"))
+
+
+@pytest.fixture(scope="module")
+def disc():
+    from superresolution_amd import Discriminator
+    torch.manual_seed(0)                      # make_golden.py: torch.manual_seed(0); Discriminator()
+    return Discriminator().cuda()
+
+
+def test_logits_and_losses_vs_reference_golden(disc, gd, golden):
+    from superresolution_amd import RelativisticAverageLoss, weights as W
+    hr = torch.from_numpy(W.synthetic_hr_batch(2, seed=1)).cuda()
+    sr = torch.from_numpy(golden["y_dense_sparse"]).cuda()
+    with torch.no_grad():
+        dr, df = disc(hr), disc(sr)
+        crit = RelativisticAverageLoss()
+        ld, lg = crit.discriminator_loss(dr, df), crit.generator_loss(dr, df)
+    assert dr.shape == (2, 1, 8, 8) and dr.dtype == torch.float32 and dr.is_contiguous()
+    e1, e2 = max_rel(dr.cpu().numpy(), gd["d_real"]), max_rel(df.cpu().numpy(), gd["d_fake"])
+    print("discriminator max rel err vs reference:", e1, e2)
+    assert e1 <= FP32_TOL and e2 <= FP32_TOL
+    assert ld.dim() == 0 and lg.dim() == 0
+    print("losses:", ld.item(), float(gd["loss_d"]), lg.item(), float(gd["loss_g"]))
+    assert abs(ld.item() - float(gd["loss_d"])) <= 1e-5
+    assert abs(lg.item() - float(gd["loss_g"])) <= 1e-5
+
+
+@pytest.mark.parametrize("hw", [(125, 125), (37, 53), (16, 9), (1, 1)])
+def test_every_layer_vs_cpu_oracle(hw):
+    """Other weights than the fixture, sizes that leave ragged pixel tiles and odd strided rows;
+    every conv output is compared (taps), not only the logits."""
+    from oracle import oracle as O
+    from superresolution_amd import Discriminator
+    torch.manual_seed(5)
+    d = Discriminator()
+    with torch.no_grad():
+        for p in d.parameters():
+            if p.dim() == 1:
+                p.uniform_(-0.1, 0.1)          # the default init zeroes every bias
+    sd = {k: v.numpy().copy() for k, v in d.state_dict().items()}
+    d = d.cuda()
+    n = 3 if hw[0] < 100 else 1
+    x = np.random.default_rng(2).random((n, 3) + hw, dtype=np.float32)
+    ref_taps = []
+    ref = O.discriminator_forward(sd, x, ref_taps)
+    with torch.no_grad():
+        y, taps = d.forward_taps(torch.from_numpy(x).cuda())
+    assert len(taps) == len(ref_taps) == 10
+    for i, (t, r) in enumerate(zip(taps, ref_taps)):
+        assert tuple(t.shape) == r.shape, i
+        err = max_rel(t.cpu().numpy(), r)
+        print("layer", i, tuple(t.shape), err)
+        assert err <= FP32_TOL, i
+    assert max_rel(y.cpu().numpy(), ref) <= FP32_TOL
+
+
+@pytest.mark.parametrize("n", [1, 5, 64])
+def test_batches_are_image_independent(disc, n):
+    x = torch.rand((n, 3, 125, 125), generator=torch.Generator().manual_seed(n)).cuda()
+    with torch.no_grad():
+        y = disc(x)
+        assert y.shape == (n, 1, 8, 8) and torch.isfinite(y).all()
+        for i in sorted({0, n // 2, n - 1}):
+            assert torch.equal(y[i:i + 1], disc(x[i:i + 1])), (n, i)
+        assert disc(x[:0]).shape == (0, 1, 8, 8)
+
+
+@pytest.mark.parametrize("nr,nf", [(128, 128), (64, 192), (1, 1), (100000, 77777)])
+def test_ragan_loss_vs_oracle(nr, nf):
+    from oracle import oracle as O
+    from superresolution_amd import RelativisticAverageLoss
+    rng = np.random.default_rng(nr + nf)
+    real = (rng.standard_normal(nr) * 3 + 0.5).astype(np.float32)
+    fake = (rng.standard_normal(nf) * 3 - 0.5).astype(np.float32)
+    real[0], fake[0] = 40.0, -40.0             # saturated logits: log1p(exp(-|x|)) must not overflow
+    for labels in ((0.9, 0.1), (1.0, 0.0)):
+        crit = RelativisticAverageLoss(*labels)
+        with torch.no_grad():
+            ld, lg = crit.both_losses(torch.from_numpy(real).cuda(), torch.from_numpy(fake).cuda())
+        rd, rg = O.ragan_losses(real, fake, *labels)
+        assert abs(ld.item() - rd) <= 1e-5 * max(1.0, abs(rd)), (ld.item(), rd)
+        assert abs(lg.item() - rg) <= 1e-5 * max(1.0, abs(rg)), (lg.item(), rg)
+
+
+def test_autograd_calls_raise_and_weight_reload(disc):
+    from superresolution_amd import RelativisticAverageLoss
+    x = torch.rand(1, 3, 125, 125, device="cuda")
+    with pytest.raises(NotImplementedError, match="no_grad"):
+        disc(x)                                 # parameters require grad and grad mode is on
+    with torch.no_grad():
+        y0 = disc(x).clone()
+        sd0 = {k: v.clone() for k, v in disc.state_dict().items()}
+        sd1 = {k: v * 0.5 for k, v in sd0.items()}
+        disc.load_state_dict(sd1)
+        y1 = disc(x).clone()
+        disc.load_state_dict(sd0)
+        y2 = disc(x)
+    assert not torch.equal(y0, y1) and torch.equal(y0, y2)
+    r = torch.zeros(4, device="cuda", requires_grad=True)
+    with pytest.raises(NotImplementedError, match="no_grad"):
+        RelativisticAverageLoss().generator_loss(r, r)
+    with pytest.raises(RuntimeError, match="Error\\(s\\) in loading state_dict for Discriminator|size mismatch"):
+        bad = dict(sd0)
+        bad["head.2.weight"] = torch.zeros(1, 128, 3, 3, device="cuda")
+        disc.load_state_dict(bad)
