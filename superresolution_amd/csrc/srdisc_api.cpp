@@ -134,6 +134,7 @@ struct srdisc_handle {
     bool committed = false;
     char* blob = nullptr;
     size_t blob_bytes = 0;
+    size_t zeros = 0;                   // kDiscZeroFloats zero floats in the blob
 };
 
 extern "C" {
@@ -203,6 +204,7 @@ int srdisc_commit_weights(srdisc_handle* h, void* stream)
         memcpy(bytes.data() + off, v.data(), v.size() * sizeof(float));
         return off;
     };
+    h->zeros = put(std::vector<float>(kDiscZeroFloats, 0.f));
     for (size_t i = 0; i < h->layers.size(); ++i) {
         Layer& l = h->layers[i];
         const std::vector<float>& w = h->tensors.at(l.key + ".weight");
@@ -277,7 +279,7 @@ int srdisc_forward(srdisc_handle* h, const float* x, float* logits, void* worksp
     int ih = hgt, iw = wid;
     for (int i = 1; i <= 8; ++i) {
         DiscConvArgs a{buf[(i - 1) & 1], buf[i & 1], dev(L[i].w), dev(L[i].bias), n, ih, iw,
-                       L[i].cin, L[i].cout, L[i].stride, kSlope};
+                       L[i].cin, L[i].cout, L[i].stride, kSlope, dev(h->zeros)};
         HIP_TRY(launch_disc_conv(a, s));
         HIP_TRY(tap(i, buf[i & 1], L[i].cout));
         ih = p.h[i];

@@ -16,6 +16,8 @@
 //   ragan_loss_kernel  both losses of RelativisticAverageLoss in one single-workgroup launch.
 #include "srgen_internal.h"
 
+#include <cstdlib>
+
 namespace srgen {
 namespace {
 
@@ -65,85 +67,129 @@ __global__ __launch_bounds__(256) void disc_stem_kernel(DiscStemArgs a, int tota
 }
 
 // ---- Cin -> Cout implicit GEMM ------------------------------------------------------------------
-// workgroup = 4 waves = 128 output pixels x 64 output channels; wave = 32 pixels (two 16-pixel
-// column groups) x 64 channels (four 16-row tiles) = 8 accumulators.  k runs over (tap, 16-channel
-// chunk); per chunk a lane loads 2 activation and 4 weight float4s for 32 MFMAs, the next chunk's
-// loads issued before the current chunk's MFMAs.
-struct Frag {
-    f32x4 x[2];
-    f32x4 w[4];
-};
-
-template <int STRIDE>
-__global__ __launch_bounds__(256, 2) void disc_conv_kernel(DiscConvArgs a, int OH, int OW, int M, int lg_nch)
+// workgroup = 4 waves = 64*G output pixels x 64 output channels; wave = 16*G pixels (G 16-pixel column
+// groups) x 64 channels (four 16-row tiles) = 4*G accumulators.  k runs over (tap, 16-channel chunk);
+// per chunk a lane loads G activation and 4 weight float4s for 16*G MFMAs, the next chunk's loads
+// issued before the current chunk's MFMAs.
+//
+// VALU instructions between MFMAs cost issue slots the matrix pipe then idles for (the first version
+// of this kernel computed the tap address and zero-masked the fragment per chunk and ran at 75 % of
+// the MFMA rate), so the chunk loop carries none: chunks advance in steps of four with immediate
+// offsets from one per-lane pointer, a lane's nine tap validities are one bit mask computed up front,
+// and an out-of-image tap points the lane at a page of zeros (DiscConvArgs::zeros) instead of
+// masking the loaded values.  Per step: one 64-bit pointer update per pixel group; per tap: a
+// select between the image address and the zero page.
+template <int STRIDE, int G>
+__global__ __launch_bounds__(256, 2) void disc_conv_kernel(DiscConvArgs a, int OH, int OW, int M, int lg_nst)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int l16 = lane & 15, kq = lane >> 4;
     const int ncb = a.Cout >> 6;
     const int cb = blockIdx.x % ncb;
     const int tile = blockIdx.x / ncb;
-    const int nch = 1 << lg_nch;
-    const int total = 9 * nch;
+    const int nst = 1 << lg_nst;               // steps (of 4 chunks = 64 input channels) per tap
+    const int total = 9 * nst;
 
-    int p[2], img[2], oy[2], ox[2];
-    bool pv[2];
+    int p[G];
+    bool pv[G];
+    unsigned vmask[G];                          // bit t: tap t of this pixel lies inside the image
+    const float* base[G];                       // address of tap (0,0), channel 4*kq (may be out of image)
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        p[g] = tile * 128 + wv * 32 + g * 16 + l16;
+    for (int g = 0; g < G; ++g) {
+        p[g] = tile * (64 * G) + wv * (16 * G) + g * 16 + l16;
         pv[g] = p[g] < M;
         const int pc = pv[g] ? p[g] : 0;
-        img[g] = pc / (OH * OW);
-        const int r = pc - img[g] * (OH * OW);
-        oy[g] = r / OW;
-        ox[g] = r - oy[g] * OW;
-    }
-    const f32x4* wp = reinterpret_cast<const f32x4*>(a.wpack) + (size_t)cb * total * 256 + lane;
-
-    auto load = [&](Frag& f, int it) {
-        const int tap = it >> lg_nch, ch = it & (nch - 1);
-        const int ky = tap / 3, kx = tap - 3 * ky;
+        const int img = pc / (OH * OW);
+        const int r = pc - img * (OH * OW);
+        const int oy = r / OW, ox = r - oy * OW;
+        const int iy0 = oy * STRIDE - 1, ix0 = ox * STRIDE - 1;
+        unsigned m = 0;
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            const int iy = oy[g] * STRIDE + ky - 1, ix = ox[g] * STRIDE + kx - 1;
-            const bool v = pv[g] && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-            const size_t off = v ? (((size_t)img[g] * a.H + iy) * a.W + ix) * a.Cin + ch * 16 + kq * 4 : 0;
-            const f32x4 t = *reinterpret_cast<const f32x4*>(a.in + off);
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            f.x[g] = v ? t : z;
+        for (int t = 0; t < 9; ++t) {
+            const int iy = iy0 + t / 3, ix = ix0 + t % 3;
+            if (pv[g] && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) m |= 1u << t;
         }
-        const f32x4* w = wp + (size_t)it * 256;
+        vmask[g] = m;
+        base[g] = a.in + (((long long)img * a.H + iy0) * a.W + ix0) * a.Cin + kq * 4;
+    }
+    const float* zero = a.zeros + kq * 4;
+    const f32x4* wp = reinterpret_cast<const f32x4*>(a.wpack) + (size_t)cb * total * 1024 + lane;
+
+    const float* cur[G];                        // this step's activation pointer (chunk 0)
+    auto set_step = [&](int st) {
+        const int tap = st >> lg_nst, c4 = st & (nst - 1);
+        const int ky = tap / 3, kx = tap - 3 * ky;
+        const int toff = (ky * a.W + kx) * a.Cin + c4 * 64;       // wave-uniform
 #pragma unroll
-        for (int s = 0; s < 4; ++s) f.w[s] = w[s * 64];
+        for (int g = 0; g < G; ++g) cur[g] = ((vmask[g] >> tap) & 1u) ? base[g] + toff : zero + c4 * 64;
+    };
+    // activation fragments: ring of four chunks, issued three chunks ahead (they come from HBM / the
+    // other XCDs' traffic); weight fragments (L2-resident: an XCD sees one or two 64-channel blocks):
+    // two buffers, one chunk ahead.  Weights are issued BEFORE the activations of the same slot: vmcnt
+    // retires in order, so waiting for w(i) must not also wait for the younger x(i+2).
+    f32x4 xb[4][G], wb[2][4];
+    auto load_x = [&](int slot, int c) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) xb[slot][g] = *reinterpret_cast<const f32x4*>(cur[g] + c * 16);
+    };
+    auto load_w = [&](int slot, int st, int c) {
+        const f32x4* w = wp + ((size_t)st * 4 + c) * 256;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) wb[slot][s] = w[s * 64];
     };
 
-    f32x4 acc[4][2];
+    f32x4 acc[4][G];
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int g = 0; g < 2; ++g) acc[s][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int g = 0; g < G; ++g) acc[s][g] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    auto mma = [&](const Frag& f) {
+    auto mma = [&](int ws, int xs) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int g = 0; g < 2; ++g)
-                    acc[s][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.w[s][j], f.x[g][j], acc[s][g], 0, 0, 0);
+                for (int g = 0; g < G; ++g)
+                    acc[s][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[ws][s][j], xb[xs][g][j], acc[s][g], 0, 0, 0);
     };
 
-    Frag f0, f1;
-    load(f0, 0);
-    // total = 9 * nch is odd only for nch == 1, which the launcher does not allow (Cin >= 32)
-    for (int it = 0; it < total; it += 2) {
-        load(f1, it + 1);
-        mma(f0);
-        if (it + 2 < total) load(f0, it + 2);
-        mma(f1);
+    // sched_barrier: keep the compiler from regrouping the loads (it otherwise clusters several chunks'
+    // loads and waits on them a few MFMAs later, exposing the latency this pipelining is there to hide)
+    set_step(0);
+    load_x(0, 0);                   // same issue order as the loop's steady state, so that the wait
+    load_x(1, 1);                   // counts the compiler derives at the loop header are the exact ones
+    load_w(0, 0, 0);
+    load_x(2, 2);
+    for (int st = 0; st < total; ++st) {
+        // the last step re-loads its own chunks instead of branching round the prefetches: with
+        // conditional loads the compiler's wait counts fall back to the most conservative path
+        const int sn = st + 1 < total ? st + 1 : st;
+        load_w(1, st, 1);
+        load_x(3, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_w(0, st, 2);
+        set_step(sn);
+        load_x(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        load_w(1, st, 3);
+        load_x(1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(0, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        load_w(0, sn, 0);
+        load_x(2, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(1, 3);
+        __builtin_amdgcn_sched_barrier(0);
     }
 
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
+    for (int g = 0; g < G; ++g) {
         if (!pv[g]) continue;
         float* o = a.out + (size_t)p[g] * a.Cout + cb * 64 + kq * 16;
         const float* b = a.bias + cb * 64 + kq * 16;
@@ -255,20 +301,30 @@ hipError_t launch_disc_stem(const DiscStemArgs& a, hipStream_t s)
 hipError_t launch_disc_conv(const DiscConvArgs& a, hipStream_t s)
 {
     if (a.N <= 0) return hipSuccess;
-    const int nch = a.Cin >> 4;
-    if (a.Cin % 32 || a.Cout % 64 || (nch & (nch - 1)) || (a.stride != 1 && a.stride != 2) || a.H < 1 || a.W < 1)
+    const int nst = a.Cin >> 6;                 // steps of 64 input channels per tap
+    if (a.Cin % 64 || a.Cin > kDiscZeroFloats || a.Cout % 64 || (nst & (nst - 1)) || !a.zeros ||
+        (a.stride != 1 && a.stride != 2) || a.H < 1 || a.W < 1)
         return hipErrorInvalidValue;
     int lg = 0;
-    while ((1 << lg) < nch) ++lg;
+    while ((1 << lg) < nst) ++lg;
     const int OH = (a.H - 1) / a.stride + 1, OW = (a.W - 1) / a.stride + 1;
     const long long M = (long long)a.N * OH * OW;
-    const long long blocks = ((M + 127) / 128) * (a.Cout >> 6);
+    // 64 pixels per wave (16 accumulators) once the launch still fills the chip several times over,
+    // 32 otherwise (small batches / the late layers)
+    const bool wide = ((M + 255) / 256) * (a.Cout >> 6) >= 2048 && !getenv("SRDISC_NARROW");
+    const int wg_px = wide ? 256 : 128;
+    const long long blocks = ((M + wg_px - 1) / wg_px) * (a.Cout >> 6);
     if (M > 0x7fffffffLL || blocks > 0x7fffffffLL || (long long)a.N * a.H * a.W > 0x7fffffffLL)
         return hipErrorInvalidValue;
-    if (a.stride == 1)
-        hipLaunchKernelGGL(disc_conv_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, a, OH, OW, (int)M, lg);
+    const dim3 grid((unsigned)blocks), block(256);
+    if (a.stride == 1 && wide)
+        hipLaunchKernelGGL((disc_conv_kernel<1, 4>), grid, block, 0, s, a, OH, OW, (int)M, lg);
+    else if (a.stride == 1)
+        hipLaunchKernelGGL((disc_conv_kernel<1, 2>), grid, block, 0, s, a, OH, OW, (int)M, lg);
+    else if (wide)
+        hipLaunchKernelGGL((disc_conv_kernel<2, 4>), grid, block, 0, s, a, OH, OW, (int)M, lg);
     else
-        hipLaunchKernelGGL(disc_conv_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, a, OH, OW, (int)M, lg);
+        hipLaunchKernelGGL((disc_conv_kernel<2, 2>), grid, block, 0, s, a, OH, OW, (int)M, lg);
     return hipGetLastError();
 }
 

@@ -108,7 +108,9 @@ struct DiscConvArgs {          // conv Cin -> Cout (Cin % 16 == 0, Cout % 64 == 
     const float* bias;         // [Cout]
     int N, H, W, Cin, Cout, stride;
     float slope;               // LeakyReLU slope
+    const float* zeros;        // kDiscZeroFloats zeros in device memory: what out-of-image taps read
 };
+constexpr int kDiscZeroFloats = 512;
 struct DiscTailArgs {          // conv Cin -> 1, stride 1, pad 1, no activation
     const float* in;           // (N,H,W,Cin), Cin % 4 == 0
     float* y;                  // (N,1,H,W)
