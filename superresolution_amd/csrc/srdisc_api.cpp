@@ -55,13 +55,22 @@ std::vector<Layer> layer_table(const srdisc_config& c)
     };
 }
 
-// stem: [k 27][co 64], k = (ky*3 + kx)*3 + ci
+// stem: [j 7][s 4][lane 64]; lane (m = lane & 15, kq = lane >> 4) of row tile s in k-step j holds
+// w[co = 16*(m >> 2) + 4*s + (m & 3)][k = 4*j + kq], k = (ky*3 + kx)*3 + ci, zero for the pad k == 27
+// (same channel permutation as pack_disc_conv: a lane ends up with 16 consecutive channels)
 std::vector<float> pack_disc_stem(const std::vector<float>& w)
 {
-    std::vector<float> p((size_t)27 * 64);
-    for (int co = 0; co < 64; ++co)
-        for (int ci = 0; ci < 3; ++ci)
-            for (int t = 0; t < 9; ++t) p[(size_t)(t * 3 + ci) * 64 + co] = w[((size_t)co * 3 + ci) * 9 + t];
+    std::vector<float> p((size_t)7 * 4 * 64, 0.f);
+    for (int j = 0; j < 7; ++j)
+        for (int s = 0; s < 4; ++s)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int m = lane & 15, kq = lane >> 4;
+                const int co = 16 * (m >> 2) + 4 * s + (m & 3);
+                const int k = 4 * j + kq;
+                if (k >= 27) continue;
+                const int t = k / 3, ci = k % 3;
+                p[((size_t)j * 4 + s) * 64 + lane] = w[((size_t)co * 3 + ci) * 9 + t];
+            }
     return p;
 }
 

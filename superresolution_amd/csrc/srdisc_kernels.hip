@@ -2,8 +2,8 @@
 // (/root/reference/Discriminator.py:17-50) and the relativistic-average loss (:53-72).
 //
 // Activations between layers are NHWC fp32.  Every conv is 3x3, pad 1 (Discriminator.py:9,23,35,37):
-//   disc_stem_kernel   3 -> 64, stride 1: VALU, weights through scalar loads (K = 27 is too thin for
-//                      MFMA tiles); reads the caller's NCHW input, writes NHWC.
+//   disc_stem_kernel   3 -> 64, stride 1: K = 27 padded to 28 on the same MFMA; reads the caller's NCHW
+//                      input, writes NHWC through an LDS transpose (the layer is store-bound).
 //   disc_conv_kernel   Cin -> Cout, stride 1 or 2: implicit GEMM on v_mfma_f32_16x16x4_f32.
 //                      A = weights (rows = 16 output channels), B = activations (columns = 16 output
 //                      pixels), so a lane ends up with 4 consecutive channels of one pixel per
@@ -26,42 +26,86 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 
 // ---- stem -------------------------------------------------------------------------------------
+// 3 -> 64 on the same MFMA, K = 27 padded to 28 = seven k-steps: lane (l16, kq) feeds k = 4*j + kq of
+// pixel l16 in step j, k = (ky*3 + kx)*3 + ci, gathered straight from the caller's NCHW planes (the
+// input is 3 floats per pixel against 64 written: the gather lives in L1).  A wave keeps its 28
+// weight values in registers and walks STEM_GROUPS consecutive 16-pixel groups.  The layer is bound
+// by its 256-byte-per-pixel output, so the accumulators (a lane holds 16 channels of one pixel: 16-byte
+// pieces 256 bytes apart across lanes) are transposed through LDS and leave as 1 KB-contiguous stores.
+constexpr int STEM_GROUPS = 8;                  // 16-pixel groups per wave
+constexpr int STEM_ROW = 272;                   // LDS row pitch in bytes: 256 + 16, conflict-free both ways
+
 __global__ __launch_bounds__(256) void disc_stem_kernel(DiscStemArgs a, int total)
 {
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= total) return;
+    __shared__ __attribute__((aligned(16))) char lds[4 * 16 * STEM_ROW];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int l16 = lane & 15, kq = lane >> 4;
     const int hw = a.H * a.W;
-    const int img = p / hw, r = p - img * hw;
-    const int y = r / a.W, x = r - y * a.W;
-    float in[27];
+
+    // weights: [j 7][s 4][lane 64], bias: the lane's 16 channels kq*16 .. kq*16 + 15
+    float w[7][4];
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
+    for (int j = 0; j < 7; ++j)
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const int iy = y + ky - 1, ix = x + kx - 1;
-            const bool v = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-            const size_t off = v ? ((size_t)img * 3 * a.H + iy) * a.W + ix : 0;
+        for (int s = 0; s < 4; ++s) w[j][s] = a.w[(j * 4 + s) * 64 + lane];
+    f32x4 bias[4];
 #pragma unroll
-            for (int ci = 0; ci < 3; ++ci) {
-                const float t = a.x[off + (v ? (size_t)ci * hw : 0)];
-                in[(ky * 3 + kx) * 3 + ci] = v ? t : 0.f;
-            }
-        }
-    float* o = a.out + (size_t)p * 64;
+    for (int s = 0; s < 4; ++s) bias[s] = *reinterpret_cast<const f32x4*>(a.bias + kq * 16 + s * 4);
+
+    // this lane's seven k's: plane/row/column offset of tap k relative to the output pixel
+    int koff[7], kdy[7], kdx[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        const int k = 4 * j + kq;
+        const int tap = k / 3, ci = k - 3 * tap;
+        const int ky = tap / 3, kx = tap - 3 * ky;
+        kdy[j] = k < 27 ? ky - 1 : -100000;     // k == 27 is the zero pad: never inside the image
+        kdx[j] = kx - 1;
+        koff[j] = (ci * a.H + ky - 1) * a.W + kx - 1;
+    }
+
+    char* my = lds + wv * 16 * STEM_ROW;
+    const int first = (blockIdx.x * 4 + wv) * (16 * STEM_GROUPS);
 #pragma unroll 1
-    for (int cg = 0; cg < 4; ++cg) {
-        float acc[16];
+    for (int gi = 0; gi < STEM_GROUPS; ++gi) {
+        const int p0 = first + gi * 16;
+        if (p0 >= total) break;                                  // wave-uniform
+        const int p = p0 + l16;
+        const bool pv = p < total;
+        const int pc = pv ? p : 0;
+        const int img = pc / hw, r = pc - img * hw;
+        const int y = r / a.W, x = r - y * a.W;
+        const float* src = a.x + (size_t)img * 3 * hw + r;
+        float xk[7];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) acc[c] = a.bias[cg * 16 + c];
+        for (int j = 0; j < 7; ++j) {
+            const int iy = y + kdy[j], ix = x + kdx[j];
+            const bool v = pv && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            const float t = src[v ? koff[j] : 0];
+            xk[j] = v ? t : 0.f;
+        }
+        f32x4 acc[4];
 #pragma unroll
-        for (int k = 0; k < 27; ++k)
+        for (int s = 0; s < 4; ++s) acc[s] = bias[s];
 #pragma unroll
-            for (int c = 0; c < 16; ++c) acc[c] = fmaf(in[k], a.w[k * 64 + cg * 16 + c], acc[c]);
+        for (int j = 0; j < 7; ++j)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            f32x4 v = {lrelu(acc[4 * q], a.slope), lrelu(acc[4 * q + 1], a.slope),
-                       lrelu(acc[4 * q + 2], a.slope), lrelu(acc[4 * q + 3], a.slope)};
-            *reinterpret_cast<f32x4*>(o + cg * 16 + 4 * q) = v;
+            for (int s = 0; s < 4; ++s)
+                acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j][s], xk[j], acc[s], 0, 0, 0);
+        // accumulator (row m = 4*kq + r of tile s, column l16) = channel kq*16 + s*4 + r of pixel l16
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const f32x4 v = {lrelu(acc[s][0], a.slope), lrelu(acc[s][1], a.slope), lrelu(acc[s][2], a.slope),
+                             lrelu(acc[s][3], a.slope)};
+            *reinterpret_cast<f32x4*>(my + l16 * STEM_ROW + kq * 64 + s * 16) = v;
+        }
+        // same wave wrote and reads (LDS executes a wave's accesses in order): no barrier
+        float* o = a.out + (size_t)p0 * 64;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int px = i * 4 + kq;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(my + px * STEM_ROW + l16 * 16);
+            if (p0 + px < total) *reinterpret_cast<f32x4*>(o + px * 64 + l16 * 4) = v;
         }
     }
 }
@@ -294,7 +338,9 @@ hipError_t launch_disc_stem(const DiscStemArgs& a, hipStream_t s)
     const long long total = (long long)a.N * a.H * a.W;
     if (total <= 0) return hipSuccess;
     if (total > 0x7fffffffLL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(disc_stem_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a, (int)total);
+    const long long per_wg = 4 * 16 * STEM_GROUPS;
+    hipLaunchKernelGGL(disc_stem_kernel, dim3((unsigned)((total + per_wg - 1) / per_wg)), dim3(256), 0, s, a,
+                       (int)total);
     return hipGetLastError();
 }
 

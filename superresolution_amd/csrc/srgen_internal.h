@@ -96,7 +96,8 @@ hipError_t launch_metrics(const float* sr, const float* hr, int n, int c, int h,
 struct DiscStemArgs {          // conv 3 -> 64, stride 1, pad 1, + LeakyReLU
     const float* x;            // (N,3,H,W) NCHW
     float* out;                // (N,H,W,64) NHWC
-    const float* w;            // [k 27][co 64], k = (ky*3 + kx)*3 + ci
+    const float* w;            // [j 7][s 4][lane 64]: w[co = 16*(m>>2) + 4*s + (m&3)][k = 4*j + (lane>>4)],
+                               // m = lane & 15, k = (ky*3 + kx)*3 + ci, k == 27 zero
     const float* bias;         // [64]
     int N, H, W;
     float slope;
