@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256, 2) void disc_conv_kernel(DiscConvArgs a, int O
     load_x(1, 1);                   // counts the compiler derives at the loop header are the exact ones
     load_w(0, 0, 0);
     load_x(2, 2);
-    for (int st = 0; st < total; ++st) {
+    auto do_step = [&](int st) {
         // the last step re-loads its own chunks instead of branching round the prefetches: with
         // conditional loads the compiler's wait counts fall back to the most conservative path
         const int sn = st + 1 < total ? st + 1 : st;
@@ -230,6 +230,14 @@ __global__ __launch_bounds__(256, 2) void disc_conv_kernel(DiscConvArgs a, int O
         __builtin_amdgcn_sched_barrier(0);
         mma(1, 3);
         __builtin_amdgcn_sched_barrier(0);
+    };
+    // three steps per trip (total = 9 * nst): at a loop header the compiler waits for every load but
+    // those of the current chunk, i.e. also for the activations issued one chunk earlier, which the
+    // ring is there to give three chunks; a longer body meets that wait once per twelve chunks
+    for (int st = 0; st < total; st += 3) {
+        do_step(st);
+        do_step(st + 1);
+        do_step(st + 2);
     }
 
 #pragma unroll
@@ -355,22 +363,29 @@ hipError_t launch_disc_conv(const DiscConvArgs& a, hipStream_t s)
     while ((1 << lg) < nst) ++lg;
     const int OH = (a.H - 1) / a.stride + 1, OW = (a.W - 1) / a.stride + 1;
     const long long M = (long long)a.N * OH * OW;
-    // 64 pixels per wave (16 accumulators) once the launch still fills the chip several times over,
-    // 32 otherwise (small batches / the late layers)
-    const bool wide = ((M + 255) / 256) * (a.Cout >> 6) >= 2048 && !getenv("SRDISC_NARROW");
+    // 64 pixels per wave (16 accumulators) when that still gives every CU a workgroup, 32 otherwise
+    // (small batches / the late layers)
+    static const int wide_min = getenv("SRDISC_WIDE_MIN") ? atoi(getenv("SRDISC_WIDE_MIN")) : 256;
+    const bool wide = ((M + 255) / 256) * (a.Cout >> 6) >= wide_min;
     const int wg_px = wide ? 256 : 128;
     const long long blocks = ((M + wg_px - 1) / wg_px) * (a.Cout >> 6);
     if (M > 0x7fffffffLL || blocks > 0x7fffffffLL || (long long)a.N * a.H * a.W > 0x7fffffffLL)
         return hipErrorInvalidValue;
     const dim3 grid((unsigned)blocks), block(256);
+    // Occupancy limiter: the kernel uses no LDS; asking for 96 KB of it keeps ONE workgroup (one wave per
+    // SIMD) on a CU.  Measured at batch 256 on the layers whose input comes from L2 (Cin >= 128): 135-140
+    // TFLOP/s that way against 107-120 with two or three workgroups per CU taking turns on the matrix
+    // pipe and evicting each other's weight fragments from L1; the prefetch ring hides the latency alone.
+    static const int lds_env = getenv("SRDISC_LDS") ? atoi(getenv("SRDISC_LDS")) : -1;
+    const int lds_pad = lds_env >= 0 ? lds_env : (wide && a.Cin >= 128 ? 96 * 1024 : 0);
     if (a.stride == 1 && wide)
-        hipLaunchKernelGGL((disc_conv_kernel<1, 4>), grid, block, 0, s, a, OH, OW, (int)M, lg);
+        hipLaunchKernelGGL((disc_conv_kernel<1, 4>), grid, block, lds_pad, s, a, OH, OW, (int)M, lg);
     else if (a.stride == 1)
-        hipLaunchKernelGGL((disc_conv_kernel<1, 2>), grid, block, 0, s, a, OH, OW, (int)M, lg);
+        hipLaunchKernelGGL((disc_conv_kernel<1, 2>), grid, block, lds_pad, s, a, OH, OW, (int)M, lg);
     else if (wide)
-        hipLaunchKernelGGL((disc_conv_kernel<2, 4>), grid, block, 0, s, a, OH, OW, (int)M, lg);
+        hipLaunchKernelGGL((disc_conv_kernel<2, 4>), grid, block, lds_pad, s, a, OH, OW, (int)M, lg);
     else
-        hipLaunchKernelGGL((disc_conv_kernel<2, 2>), grid, block, 0, s, a, OH, OW, (int)M, lg);
+        hipLaunchKernelGGL((disc_conv_kernel<2, 2>), grid, block, lds_pad, s, a, OH, OW, (int)M, lg);
     return hipGetLastError();
 }
 
