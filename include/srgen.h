@@ -144,6 +144,13 @@ SRGEN_API int srgen_metrics_scratch_bytes(int n, int c, int hgt, int wid, size_t
 SRGEN_API int srgen_metrics(const float* sr, const float* hr, int n, int c, int hgt, int wid,
                   float* out3, void* scratch, size_t scratch_bytes, void* stream);
 
+/* Replaces: the pixel terms of the training losses (train.py:94 and :170-172): weighted_l1(sr, hr)
+ * (train.py:18-20: mean of |sr - hr| weighted 10 where hr > 0.01, 1 elsewhere) next to ssim(sr, hr).
+ * Same pass, arguments and scratch as srgen_metrics; out4 = {psnr, ssim, l1, weighted_l1}.
+ * Forward values only (the reference differentiates through them). */
+SRGEN_API int srgen_pixel_losses(const float* sr, const float* hr, int n, int c, int hgt, int wid,
+                                 float* out4, void* scratch, size_t scratch_bytes, void* stream);
+
 /* ---- Discriminator + relativistic-average GAN loss (forward values) ------------------------
  * SURVEY.md 8(f) "next" row 3: the PatchGAN critic the reference's GAN phase evaluates on hr and on
  * generator output (train.py:145-176).  Same conventions as above; fp32 only.  These entry points

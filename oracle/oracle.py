@@ -278,3 +278,10 @@ def ragan_losses(real, fake, real_label=0.9, fake_label=0.1):
     rf, fr = r - f.mean(), f - r.mean()                     # :61-62, :68-69
     return ((bce(rf, real_label) + bce(fr, fake_label)) / 2,      # :63-65
             (bce(rf, 0.0) + bce(fr, 1.0)) / 2)                    # :70-72
+
+
+def weighted_l1(sr, hr) -> float:
+    """train.py:18-20: weight = (hr > 0.01).float() * 9 + 1; (weight * (sr - hr).abs()).mean(), in fp64."""
+    sr, hr = np.asarray(sr, np.float64), np.asarray(hr, np.float64)
+    weight = (np.asarray(hr, np.float32) > np.float32(0.01)).astype(np.float64) * 9 + 1
+    return float((weight * np.abs(sr - hr)).mean())

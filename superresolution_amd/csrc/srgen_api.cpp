@@ -682,19 +682,31 @@ int srgen_normalize(const float* x, void* y, size_t numel, float hr_max, int out
 int srgen_metrics_scratch_bytes(int n, int c, int hgt, int wid, size_t* bytes)
 {
     if (!bytes || n <= 0 || c <= 0 || hgt <= 0 || wid <= 0) return fail(SRGEN_E_INVALID, "bad metrics shape");
-    *bytes = align256(metrics_scratch_bytes(n, c, hgt, wid));
+    *bytes = align256(metrics_scratch_bytes(n, c, hgt, wid, 4));      // covers srgen_pixel_losses too
+    return SRGEN_OK;
+}
+
+static int run_metrics(const float* sr, const float* hr, int n, int c, int hgt, int wid, float* out, int nout,
+                       void* scratch, size_t scratch_bytes, void* stream)
+{
+    if (!sr || !hr || !out || !scratch) return fail(SRGEN_E_INVALID, "NULL argument");
+    if (n <= 0 || c <= 0 || hgt <= 0 || wid <= 0) return fail(SRGEN_E_INVALID, "bad metrics shape");
+    if (scratch_bytes < metrics_scratch_bytes(n, c, hgt, wid, nout))
+        return fail(SRGEN_E_WORKSPACE, "metrics scratch too small");
+    HIP_TRY(launch_metrics(sr, hr, n, c, hgt, wid, out, scratch, nout, (hipStream_t)stream));
     return SRGEN_OK;
 }
 
 int srgen_metrics(const float* sr, const float* hr, int n, int c, int hgt, int wid, float* out3,
                   void* scratch, size_t scratch_bytes, void* stream)
 {
-    if (!sr || !hr || !out3 || !scratch) return fail(SRGEN_E_INVALID, "NULL argument");
-    if (n <= 0 || c <= 0 || hgt <= 0 || wid <= 0) return fail(SRGEN_E_INVALID, "bad metrics shape");
-    if (scratch_bytes < metrics_scratch_bytes(n, c, hgt, wid))
-        return fail(SRGEN_E_WORKSPACE, "metrics scratch too small");
-    HIP_TRY(launch_metrics(sr, hr, n, c, hgt, wid, out3, scratch, (hipStream_t)stream));
-    return SRGEN_OK;
+    return run_metrics(sr, hr, n, c, hgt, wid, out3, 3, scratch, scratch_bytes, stream);
+}
+
+int srgen_pixel_losses(const float* sr, const float* hr, int n, int c, int hgt, int wid, float* out4,
+                       void* scratch, size_t scratch_bytes, void* stream)
+{
+    return run_metrics(sr, hr, n, c, hgt, wid, out4, 4, scratch, scratch_bytes, stream);
 }
 
 }  // extern "C"

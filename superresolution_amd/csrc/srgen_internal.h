@@ -88,9 +88,10 @@ hipError_t launch_nhwc_to_nchw_f32(const void* in, int in_is_bf16, float* out, i
 hipError_t launch_bilinear(const float* x, float* y, int planes, int h, int w, int oh, int ow,
                            hipStream_t s);
 hipError_t launch_normalize(const float* x, void* y, size_t numel, float hr_max, int out_bf16, hipStream_t s);
-size_t metrics_scratch_bytes(int n, int c, int h, int w);
+// nout = 3: {psnr, ssim, l1}; nout = 4: additionally weighted_l1 (train.py:18-20)
+size_t metrics_scratch_bytes(int n, int c, int h, int w, int nout);
 hipError_t launch_metrics(const float* sr, const float* hr, int n, int c, int h, int w,
-                          float* out3, void* scratch, hipStream_t s);
+                          float* out, void* scratch, int nout, hipStream_t s);
 
 // ---- discriminator (Discriminator.py:17-50): NHWC fp32 activations (srdisc_kernels.hip) ---------
 struct DiscStemArgs {          // conv 3 -> 64, stride 1, pad 1, + LeakyReLU

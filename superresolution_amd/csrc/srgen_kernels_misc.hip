@@ -132,13 +132,16 @@ hipError_t launch_bilinear(const float* x, float* y, int planes, int h, int w, i
 // `scratch`, and a single-workgroup second kernel adds them in fixed order in fp64.
 constexpr int MT = 32, MH = MT + 10;
 
+// NOUT == 4 adds the GAN/pre-train pixel loss weighted_l1 (train.py:18-20): |sr - hr| weighted 10 where
+// hr > 0.01 and 1 elsewhere, as a fourth partial sum.
+template <int NOUT>
 __global__ __launch_bounds__(256) void metrics_tile_kernel(const float* __restrict__ sr,
                                                            const float* __restrict__ hr, int h, int w,
                                                            int tiles_x, int tiles_y, float* scratch)
 {
     __shared__ float a[MH][MH + 1], b[MH][MH + 1];
     __shared__ float hq[5][MH][MT + 1];
-    __shared__ float red[3][4];
+    __shared__ float red[4][4];
     float g[11];
     {   // utils.py:12-16: fp32 gaussian, sigma 1.5, normalised
         float s = 0.f;
@@ -173,7 +176,7 @@ __global__ __launch_bounds__(256) void metrics_tile_kernel(const float* __restri
         hq[0][r][c] = mx; hq[1][r][c] = my; hq[2][r][c] = xx; hq[3][r][c] = yy; hq[4][r][c] = xy;
     }
     __syncthreads();
-    float se = 0.f, ae = 0.f, ss = 0.f;
+    float se = 0.f, ae = 0.f, ss = 0.f, wl = 0.f;
     for (int i = threadIdx.x; i < MT * MT; i += 256) {
         const int r = i / MT, c = i - r * MT;
         const int gy = ty * MT + r, gx = tx * MT + c;
@@ -191,34 +194,39 @@ __global__ __launch_bounds__(256) void metrics_tile_kernel(const float* __restri
             float den = (mx * mx + my * my + c1) * (sxx + syy + c2);
             den = den < 1e-8f ? 1e-8f : den;
             ss += num / den;
-            const float d = a[r + 5][c + 5] - b[r + 5][c + 5];
+            const float hv = b[r + 5][c + 5];
+            const float d = a[r + 5][c + 5] - hv;
             se += d * d; ae += fabsf(d);
+            if (NOUT == 4) wl += ((hv > 0.01f ? 1.f : 0.f) * 9.f + 1.f) * fabsf(d);     // train.py:19-20
         }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         se += __shfl_xor(se, off); ae += __shfl_xor(ae, off); ss += __shfl_xor(ss, off);
+        if (NOUT == 4) wl += __shfl_xor(wl, off);
     }
     const int wv = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { red[0][wv] = se; red[1][wv] = ae; red[2][wv] = ss; }
+    if ((threadIdx.x & 63) == 0) { red[0][wv] = se; red[1][wv] = ae; red[2][wv] = ss; red[3][wv] = wl; }
     __syncthreads();
-    if (threadIdx.x < 3)
-        scratch[(size_t)blockIdx.x * 3 + threadIdx.x] =
+    if (threadIdx.x < NOUT)
+        scratch[(size_t)blockIdx.x * NOUT + threadIdx.x] =
             (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
 }
 
+template <int NOUT>
 __global__ __launch_bounds__(256) void metrics_final_kernel(const float* scratch, int nblocks,
                                                             double total, float* out3)
 {
-    __shared__ double red[3][256];
-    double s[3] = {0, 0, 0};
+    __shared__ double red[NOUT][256];
+    double s[NOUT];
+    for (int k = 0; k < NOUT; ++k) s[k] = 0.0;
     for (int i = threadIdx.x; i < nblocks; i += 256)
-        for (int k = 0; k < 3; ++k) s[k] += (double)scratch[(size_t)i * 3 + k];
-    for (int k = 0; k < 3; ++k) red[k][threadIdx.x] = s[k];
+        for (int k = 0; k < NOUT; ++k) s[k] += (double)scratch[(size_t)i * NOUT + k];
+    for (int k = 0; k < NOUT; ++k) red[k][threadIdx.x] = s[k];
     __syncthreads();
     for (int st = 128; st > 0; st >>= 1) {
         if (threadIdx.x < st)
-            for (int k = 0; k < 3; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + st];
+            for (int k = 0; k < NOUT; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + st];
         __syncthreads();
     }
     if (threadIdx.x == 0) {
@@ -226,6 +234,7 @@ __global__ __launch_bounds__(256) void metrics_final_kernel(const float* scratch
         out3[0] = (mse == 0.0) ? 100.f : (float)(10.0 * log10(1.0 / mse));   // utils.py:7-9
         out3[1] = (float)(red[2][0] / total);
         out3[2] = (float)(red[1][0] / total);
+        if (NOUT == 4) out3[3] = (float)(red[NOUT - 1][0] / total);
     }
 }
 
@@ -234,23 +243,31 @@ static inline int metric_blocks(int n, int c, int h, int w)
     return n * c * ((h + MT - 1) / MT) * ((w + MT - 1) / MT);
 }
 
-size_t metrics_scratch_bytes(int n, int c, int h, int w)
+size_t metrics_scratch_bytes(int n, int c, int h, int w, int nout)
 {
-    return (size_t)metric_blocks(n, c, h, w) * 3 * sizeof(float);
+    return (size_t)metric_blocks(n, c, h, w) * nout * sizeof(float);
 }
 
-hipError_t launch_metrics(const float* sr, const float* hr, int n, int c, int h, int w, float* out3,
-                          void* scratch, hipStream_t s)
+template <int NOUT>
+static hipError_t launch_metrics_n(const float* sr, const float* hr, int n, int c, int h, int w, float* out,
+                                   void* scratch, hipStream_t s)
 {
     const int tiles_x = (w + MT - 1) / MT, tiles_y = (h + MT - 1) / MT;
     const int nb = metric_blocks(n, c, h, w);
-    hipLaunchKernelGGL(metrics_tile_kernel, dim3((unsigned)nb), dim3(256), 0, s, sr, hr, h, w, tiles_x,
+    hipLaunchKernelGGL(metrics_tile_kernel<NOUT>, dim3((unsigned)nb), dim3(256), 0, s, sr, hr, h, w, tiles_x,
                        tiles_y, (float*)scratch);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(metrics_final_kernel, dim3(1), dim3(256), 0, s, (const float*)scratch, nb,
-                       (double)n * c * h * w, out3);
+    hipLaunchKernelGGL(metrics_final_kernel<NOUT>, dim3(1), dim3(256), 0, s, (const float*)scratch, nb,
+                       (double)n * c * h * w, out);
     return hipGetLastError();
+}
+
+hipError_t launch_metrics(const float* sr, const float* hr, int n, int c, int h, int w, float* out,
+                          void* scratch, int nout, hipStream_t s)
+{
+    return nout == 4 ? launch_metrics_n<4>(sr, hr, n, c, h, w, out, scratch, s)
+                     : launch_metrics_n<3>(sr, hr, n, c, h, w, out, scratch, s);
 }
 
 }  // namespace srgen

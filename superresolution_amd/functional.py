@@ -54,3 +54,27 @@ def batch_metrics(sr: torch.Tensor, hr: torch.Tensor) -> torch.Tensor:
         _lib.check(L.srgen_metrics(sr.data_ptr(), hr.data_ptr(), n, c, h, w, out.data_ptr(), scratch.data_ptr(),
                                    scratch.numel(), _stream(sr)))
     return out
+
+
+def pixel_losses(sr: torch.Tensor, hr: torch.Tensor) -> torch.Tensor:
+    """float32 device tensor [psnr, ssim, l1, weighted_l1] over the whole batch: ``batch_metrics`` plus
+    the reference's ``weighted_l1`` (``train.py:18-20``) from the same pass.  With it the pixel terms of
+    the training losses are ``out[3] + w * (1 - out[1])`` (``train.py:94,170-172``).  Forward values only."""
+    sr, hr = _need_cuda_f32("sr", sr), _need_cuda_f32("hr", hr)
+    if sr.shape != hr.shape or sr.dim() != 4:
+        raise RuntimeError(f"sr {tuple(sr.shape)} and hr {tuple(hr.shape)} must be equal 4D shapes")
+    n, c, h, w = sr.shape
+    L = _lib.lib()
+    need = ctypes.c_size_t()
+    _lib.check(L.srgen_metrics_scratch_bytes(n, c, h, w, ctypes.byref(need)))
+    scratch = torch.empty(need.value, dtype=torch.uint8, device=sr.device)
+    out = torch.empty(4, dtype=torch.float32, device=sr.device)
+    with torch.cuda.device(sr.device):
+        _lib.check(L.srgen_pixel_losses(sr.data_ptr(), hr.data_ptr(), n, c, h, w, out.data_ptr(),
+                                        scratch.data_ptr(), scratch.numel(), _stream(sr)))
+    return out
+
+
+def weighted_l1(sr: torch.Tensor, hr: torch.Tensor) -> torch.Tensor:
+    """``train.py:18-20`` as a 0-dim device tensor (forward value)."""
+    return pixel_losses(sr, hr)[3]

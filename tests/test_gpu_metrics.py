@@ -35,6 +35,28 @@ def test_metrics_kernel_vs_oracle_ragged_shape():
     assert abs(m[0] - ps) <= 1e-3 and abs(m[1] - ss) <= 1e-5 and abs(m[2] - l1) <= 1e-6
 
 
+def test_pixel_losses_weighted_l1(golden, golden_metrics):
+    """weighted_l1 (train.py:18-20) from the metrics pass: against the oracle's fp64 restatement and,
+    as the expression is two lines of torch, against torch itself; the first three outputs must be
+    batch_metrics' bit for bit (same pass, same reduction order).  The fixtures hold no weighted_l1
+    value from the reference run: that number is pinned by the torch expression only."""
+    from oracle import oracle as O
+    from superresolution_amd import batch_metrics, pixel_losses, weighted_l1, weights as W
+    hr = torch.from_numpy(W.synthetic_hr_batch(2, seed=1)).cuda()
+    sr = torch.from_numpy(golden["y_dense_sparse"]).cuda()
+    rng = np.random.default_rng(4)
+    a = torch.from_numpy(rng.random((3, 2, 37, 70), dtype=np.float32)).cuda()
+    b = torch.from_numpy((rng.random((3, 2, 37, 70), dtype=np.float32) * 0.03)).cuda()   # straddles 0.01
+    for s, h in ((sr, hr), (a, b)):
+        out = pixel_losses(s, h)
+        assert out.shape == (4,) and torch.equal(out[:3], batch_metrics(s, h))
+        ref = O.weighted_l1(s.cpu().numpy(), h.cpu().numpy())
+        tref = (((h > 0.01).float() * 9 + 1) * (s - h).abs()).mean().item()
+        assert abs(out[3].item() - ref) <= 1e-6 * max(1.0, abs(ref)), (out[3].item(), ref)
+        assert abs(out[3].item() - tref) <= 2e-6 * max(1.0, abs(tref))
+        assert weighted_l1(s, h).item() == out[3].item()
+
+
 def test_bilinear_resize_matches_interpolate():
     """Optional op: same numbers as F.interpolate(bilinear, align_corners=False)."""
     from superresolution_amd import bilinear_resize
