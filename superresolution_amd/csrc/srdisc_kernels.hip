@@ -123,49 +123,58 @@ __global__ __launch_bounds__(256) void disc_stem_kernel(DiscStemArgs a, int tota
 // and an out-of-image tap points the lane at a page of zeros (DiscConvArgs::zeros) instead of
 // masking the loaded values.  Per step: one 64-bit pointer update per pixel group; per tap: a
 // select between the image address and the zero page.
+template <int G>
+struct ConvTile {
+    int p[G];                   // output pixel of each 16-pixel group (may lie past M)
+    unsigned vmask[G];          // bit t: tap t of that pixel lies inside the image (0 past M)
+    const float* base[G];       // address of tap (0,0), channel 4*kq (may be out of image)
+    const f32x4* wp;            // this lane's weight fragments of the tile's 64-channel block
+    int cb;
+};
+
 template <int STRIDE, int G>
-__global__ __launch_bounds__(256, 2) void disc_conv_kernel(DiscConvArgs a, int OH, int OW, int M, int lg_nst)
+__global__ __launch_bounds__(256, G == 4 ? 1 : 2) void disc_conv_kernel(DiscConvArgs a, int OH, int OW, int M,
+                                                                        int lg_nst, int ntiles)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int l16 = lane & 15, kq = lane >> 4;
     const int ncb = a.Cout >> 6;
-    const int cb = blockIdx.x % ncb;
-    const int tile = blockIdx.x / ncb;
     const int nst = 1 << lg_nst;               // steps (of 4 chunks = 64 input channels) per tap
     const int total = 9 * nst;
-
-    int p[G];
-    bool pv[G];
-    unsigned vmask[G];                          // bit t: tap t of this pixel lies inside the image
-    const float* base[G];                       // address of tap (0,0), channel 4*kq (may be out of image)
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        p[g] = tile * (64 * G) + wv * (16 * G) + g * 16 + l16;
-        pv[g] = p[g] < M;
-        const int pc = pv[g] ? p[g] : 0;
-        const int img = pc / (OH * OW);
-        const int r = pc - img * (OH * OW);
-        const int oy = r / OW, ox = r - oy * OW;
-        const int iy0 = oy * STRIDE - 1, ix0 = ox * STRIDE - 1;
-        unsigned m = 0;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int iy = iy0 + t / 3, ix = ix0 + t % 3;
-            if (pv[g] && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) m |= 1u << t;
-        }
-        vmask[g] = m;
-        base[g] = a.in + (((long long)img * a.H + iy0) * a.W + ix0) * a.Cin + kq * 4;
-    }
     const float* zero = a.zeros + kq * 4;
-    const f32x4* wp = reinterpret_cast<const f32x4*>(a.wpack) + (size_t)cb * total * 1024 + lane;
 
-    const float* cur[G];                        // this step's activation pointer (chunk 0)
-    auto set_step = [&](int st) {
+    auto setup = [&](ConvTile<G>& T, int t) {
+        T.cb = t % ncb;
+        const int tile = t / ncb;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int p = tile * (64 * G) + wv * (16 * G) + g * 16 + l16;
+            const bool pv = p < M;
+            const int pc = pv ? p : 0;
+            const int img = pc / (OH * OW);
+            const int r = pc - img * (OH * OW);
+            const int oy = r / OW, ox = r - oy * OW;
+            const int iy0 = oy * STRIDE - 1, ix0 = ox * STRIDE - 1;
+            unsigned m = 0;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const int iy = iy0 + k / 3, ix = ix0 + k % 3;
+                if (pv && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) m |= 1u << k;
+            }
+            T.p[g] = p;
+            T.vmask[g] = m;
+            T.base[g] = a.in + (((long long)img * a.H + iy0) * a.W + ix0) * a.Cin + kq * 4;
+        }
+        T.wp = reinterpret_cast<const f32x4*>(a.wpack) + (size_t)T.cb * total * 1024 + lane;
+    };
+
+    const float* cur[G];                        // the activation pointers (chunk 0) of the step being loaded
+    auto set_step = [&](const ConvTile<G>& T, int st) {
         const int tap = st >> lg_nst, c4 = st & (nst - 1);
         const int ky = tap / 3, kx = tap - 3 * ky;
         const int toff = (ky * a.W + kx) * a.Cin + c4 * 64;       // wave-uniform
 #pragma unroll
-        for (int g = 0; g < G; ++g) cur[g] = ((vmask[g] >> tap) & 1u) ? base[g] + toff : zero + c4 * 64;
+        for (int g = 0; g < G; ++g) cur[g] = ((T.vmask[g] >> tap) & 1u) ? T.base[g] + toff : zero + c4 * 64;
     };
     // activation fragments: ring of four chunks, issued three chunks ahead (they come from HBM / the
     // other XCDs' traffic); weight fragments (L2-resident: an XCD sees one or two 64-channel blocks):
@@ -176,18 +185,19 @@ __global__ __launch_bounds__(256, 2) void disc_conv_kernel(DiscConvArgs a, int O
 #pragma unroll
         for (int g = 0; g < G; ++g) xb[slot][g] = *reinterpret_cast<const f32x4*>(cur[g] + c * 16);
     };
-    auto load_w = [&](int slot, int st, int c) {
+    auto load_w = [&](int slot, const f32x4* wp, int st, int c) {
         const f32x4* w = wp + ((size_t)st * 4 + c) * 256;
 #pragma unroll
         for (int s = 0; s < 4; ++s) wb[slot][s] = w[s * 64];
     };
 
     f32x4 acc[4][G];
+    auto clear = [&]() {
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+        for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int g = 0; g < G; ++g) acc[s][g] = f32x4{0.f, 0.f, 0.f, 0.f};
-
+            for (int g = 0; g < G; ++g) acc[s][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
     auto mma = [&](int ws, int xs) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -198,60 +208,81 @@ __global__ __launch_bounds__(256, 2) void disc_conv_kernel(DiscConvArgs a, int O
                     acc[s][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[ws][s][j], xb[xs][g][j], acc[s][g], 0, 0, 0);
     };
 
-    // sched_barrier: keep the compiler from regrouping the loads (it otherwise clusters several chunks'
-    // loads and waits on them a few MFMAs later, exposing the latency this pipelining is there to hide)
-    set_step(0);
-    load_x(0, 0);                   // same issue order as the loop's steady state, so that the wait
-    load_x(1, 1);                   // counts the compiler derives at the loop header are the exact ones
-    load_w(0, 0, 0);
-    load_x(2, 2);
-    auto do_step = [&](int st) {
-        // the last step re-loads its own chunks instead of branching round the prefetches: with
-        // conditional loads the compiler's wait counts fall back to the most conservative path
-        const int sn = st + 1 < total ? st + 1 : st;
-        load_w(1, st, 1);
+    // One step = four chunks of tile T at step st; its prefetches reach into step sn of tile N (N is T
+    // except on a tile's last step, where it is the workgroup's next tile: the pipeline never drains
+    // between tiles).  sched_barrier: keep the compiler from regrouping the loads (it otherwise
+    // clusters several chunks' loads and waits on them a few MFMAs later).
+    auto do_step = [&](const ConvTile<G>& T, int st, const ConvTile<G>& N, int sn) {
+        load_w(1, T.wp, st, 1);
         load_x(3, 3);
         __builtin_amdgcn_sched_barrier(0);
         mma(0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        load_w(0, st, 2);
-        set_step(sn);
+        load_w(0, T.wp, st, 2);
+        set_step(N, sn);
         load_x(0, 0);
         __builtin_amdgcn_sched_barrier(0);
         mma(1, 1);
         __builtin_amdgcn_sched_barrier(0);
-        load_w(1, st, 3);
+        load_w(1, T.wp, st, 3);
         load_x(1, 1);
         __builtin_amdgcn_sched_barrier(0);
         mma(0, 2);
         __builtin_amdgcn_sched_barrier(0);
-        load_w(0, sn, 0);
+        load_w(0, N.wp, sn, 0);
         load_x(2, 2);
         __builtin_amdgcn_sched_barrier(0);
         mma(1, 3);
         __builtin_amdgcn_sched_barrier(0);
     };
-    // three steps per trip (total = 9 * nst): at a loop header the compiler waits for every load but
-    // those of the current chunk, i.e. also for the activations issued one chunk earlier, which the
-    // ring is there to give three chunks; a longer body meets that wait once per twelve chunks
-    for (int st = 0; st < total; st += 3) {
-        do_step(st);
-        do_step(st + 1);
-        do_step(st + 2);
-    }
-
+    auto epilogue = [&](const ConvTile<G>& T) {
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-        if (!pv[g]) continue;
-        float* o = a.out + (size_t)p[g] * a.Cout + cb * 64 + kq * 16;
-        const float* b = a.bias + cb * 64 + kq * 16;
+        for (int g = 0; g < G; ++g) {
+            if (T.p[g] >= M) continue;
+            float* o = a.out + (size_t)T.p[g] * a.Cout + T.cb * 64 + kq * 16;
+            const float* b = a.bias + T.cb * 64 + kq * 16;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(b + s * 4);
-            f32x4 r = acc[s][g] + bv;
-            r = f32x4{lrelu(r[0], a.slope), lrelu(r[1], a.slope), lrelu(r[2], a.slope), lrelu(r[3], a.slope)};
-            *reinterpret_cast<f32x4*>(o + s * 4) = r;
+            for (int s = 0; s < 4; ++s) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(b + s * 4);
+                f32x4 r = acc[s][g] + bv;
+                r = f32x4{lrelu(r[0], a.slope), lrelu(r[1], a.slope), lrelu(r[2], a.slope), lrelu(r[3], a.slope)};
+                *reinterpret_cast<f32x4*>(o + s * 4) = r;
+            }
         }
+    };
+
+    // Persistent: a workgroup walks tiles blockIdx.x, + gridDim.x, ...  The tile loop is rotated by one
+    // step -- its body is steps 1 .. total-1 of a tile, the epilogue, and step 0 of the next tile -- so
+    // that the conservative wait the compiler places at a loop header (everything but the current
+    // chunk's loads) never sits right behind the epilogue's stores or the next tile's first loads.
+    // Inner trips of three steps for the same reason (one such wait per twelve chunks).
+    ConvTile<G> T;
+    setup(T, blockIdx.x);
+    set_step(T, 0);
+    load_x(0, 0);
+    load_x(1, 1);
+    load_w(0, T.wp, 0, 0);
+    load_x(2, 2);
+    clear();
+    do_step(T, 0, T, 1);
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        do_step(T, 1, T, 2);
+        do_step(T, 2, T, 3);
+        for (int st = 3; st < total - 3; st += 3) {
+            do_step(T, st, T, st + 1);
+            do_step(T, st + 1, T, st + 2);
+            do_step(T, st + 2, T, st + 3);
+        }
+        do_step(T, total - 3, T, total - 2);
+        do_step(T, total - 2, T, total - 1);
+        const int tn = t + gridDim.x;
+        ConvTile<G> N;
+        setup(N, tn < ntiles ? tn : t);         // past the last tile: harmless re-loads of this one
+        do_step(T, total - 1, N, 0);
+        epilogue(T);
+        T = N;
+        clear();
+        if (tn < ntiles) do_step(T, 0, T, 1);
     }
 }
 
@@ -371,21 +402,30 @@ hipError_t launch_disc_conv(const DiscConvArgs& a, hipStream_t s)
     const long long blocks = ((M + wg_px - 1) / wg_px) * (a.Cout >> 6);
     if (M > 0x7fffffffLL || blocks > 0x7fffffffLL || (long long)a.N * a.H * a.W > 0x7fffffffLL)
         return hipErrorInvalidValue;
-    const dim3 grid((unsigned)blocks), block(256);
-    // Occupancy limiter: the kernel uses no LDS; asking for 96 KB of it keeps ONE workgroup (one wave per
-    // SIMD) on a CU.  Measured at batch 256 on the layers whose input comes from L2 (Cin >= 128): 135-140
-    // TFLOP/s that way against 107-120 with two or three workgroups per CU taking turns on the matrix
-    // pipe and evicting each other's weight fragments from L1; the prefetch ring hides the latency alone.
-    static const int lds_env = getenv("SRDISC_LDS") ? atoi(getenv("SRDISC_LDS")) : -1;
-    const int lds_pad = lds_env >= 0 ? lds_env : (wide && a.Cin >= 128 ? 96 * 1024 : 0);
+    // Occupancy: ONE workgroup (one wave per SIMD) per CU for the 64-pixel variant -- its 268 registers
+    // allow no more, and that is the fast point: at batch 256 the L2-fed layers ran 135-140 TFLOP/s that
+    // way against 107-120 with two or three workgroups per CU taking turns on the matrix pipe and
+    // evicting each other's weight fragments from L1; the prefetch ring hides the latency alone.
+    // (SRDISC_LDS reserves unused LDS as an occupancy limiter for experiments with the 32-pixel variant.)
+    static const int lds_env = getenv("SRDISC_LDS") ? atoi(getenv("SRDISC_LDS")) : 0;
+    const int lds_pad = lds_env;
+    int dev = 0, cus = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess) return e;
+    static const int wg_per_cu_env = getenv("SRDISC_WGS") ? atoi(getenv("SRDISC_WGS")) : 0;
+    const int per_cu = wg_per_cu_env > 0 ? wg_per_cu_env : (wide ? 1 : 2);
+    const long long resident = (long long)cus * per_cu;
+    const dim3 grid((unsigned)(blocks < resident ? blocks : resident)), block(256);
+    const int ntiles = (int)blocks;
     if (a.stride == 1 && wide)
-        hipLaunchKernelGGL((disc_conv_kernel<1, 4>), grid, block, lds_pad, s, a, OH, OW, (int)M, lg);
+        hipLaunchKernelGGL((disc_conv_kernel<1, 4>), grid, block, lds_pad, s, a, OH, OW, (int)M, lg, ntiles);
     else if (a.stride == 1)
-        hipLaunchKernelGGL((disc_conv_kernel<1, 2>), grid, block, lds_pad, s, a, OH, OW, (int)M, lg);
+        hipLaunchKernelGGL((disc_conv_kernel<1, 2>), grid, block, lds_pad, s, a, OH, OW, (int)M, lg, ntiles);
     else if (wide)
-        hipLaunchKernelGGL((disc_conv_kernel<2, 4>), grid, block, lds_pad, s, a, OH, OW, (int)M, lg);
+        hipLaunchKernelGGL((disc_conv_kernel<2, 4>), grid, block, lds_pad, s, a, OH, OW, (int)M, lg, ntiles);
     else
-        hipLaunchKernelGGL((disc_conv_kernel<2, 2>), grid, block, lds_pad, s, a, OH, OW, (int)M, lg);
+        hipLaunchKernelGGL((disc_conv_kernel<2, 2>), grid, block, lds_pad, s, a, OH, OW, (int)M, lg, ntiles);
     return hipGetLastError();
 }
 
