@@ -73,6 +73,9 @@ hipError_t launch_conv3x3_f32(const Conv3x3Args& a, hipStream_t s);
 // as float4 units [cb][nu 4][ci chunk 6][xi 4][ci/4 4][co 96]; needs Conv3x3Args::zeros; same
 // pool_partial tiling as the direct kernel
 hipError_t launch_conv3x3_f32_wino(const Conv3x3Args& a, hipStream_t s);
+// the same conv with every operand in registers (srgen_conv3x3_f32_wreg.hip): no LDS; wpack = U packed as
+// float4 units [nu 4][chunk 6][xi 4][s 6][lane 64]; 64x64 images, PReLU or residual epilogue
+hipError_t launch_conv3x3_f32_wreg(const Conv3x3Args& a, hipStream_t s);
 constexpr size_t kWinoZeroBytes = 64 * 96 * 4;        // one 64-pixel row of 96 channels
 hipError_t launch_chan_attn_f32(const ChanAttnArgs& a, hipStream_t s);
 hipError_t launch_head_f32(const HeadArgs& a, hipStream_t s);

@@ -48,7 +48,8 @@ int main(int argc, char** argv)
     const int rounds = argc > 2 ? atoi(argv[2]) : 5;
     const int launches = argc > 3 ? atoi(argv[3]) : 20;
     const int mode = argc > 4 ? atoi(argv[4]) : 1;
-    const bool use_wino = argc > 5 ? atoi(argv[5]) != 0 : true;      // variant "v2" = Winograd kernel
+    const int variant = argc > 5 ? atoi(argv[5]) : 1;      // "v2" = 0: direct again, 1: Winograd (LDS), 2: Winograd (registers)
+    const bool use_wino = variant == 1;
     const int H = mode == 3 ? 128 : 64;
     const int cb = mode == 2 ? 4 : 1;
     const size_t in_elems = (size_t)N * H * H * 96;
@@ -97,6 +98,30 @@ int main(int argc, char** argv)
                         }
                 }
     }
+    // register-Winograd pack: float4 units [nu 4][chunk 6][xi 4][s 6][lane 64]; lane (m = lane & 15, kq = lane >> 4)
+    // holds U[xi][nu][co = 24*(m >> 2) + 4*s + (m & 3)][ci = 16*chunk + 4*kq + j]
+    std::vector<float> h_u2((size_t)16 * 96 * 96);
+    if (cb == 1) {
+        const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+        for (int nu = 0; nu < 4; ++nu)
+            for (int chunk = 0; chunk < 6; ++chunk)
+                for (int xi = 0; xi < 4; ++xi)
+                    for (int sx = 0; sx < 6; ++sx)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int j = 0; j < 4; ++j) {
+                                const int m = lane & 15, kq = lane >> 4;
+                                const int co = 24 * (m >> 2) + 4 * sx + (m & 3), ci = 16 * chunk + 4 * kq + j;
+                                double u = 0;
+                                for (int a = 0; a < 3; ++a)
+                                    for (int c = 0; c < 3; ++c)
+                                        u += G[xi][a] * G[nu][c] *
+                                             h_w[((((size_t)(a * 3 + c)) * 24 + ci / 4) * 96 + co) * 4 + (ci & 3)];
+                                h_u2[((((((size_t)nu * 6 + chunk) * 4 + xi) * 6 + sx) * 64 + lane) * 4) + j] = (float)u;
+                            }
+    }
+    float* d_u2;
+    CK(hipMalloc(&d_u2, h_u2.size() * 4));
+    CK(hipMemcpy(d_u2, h_u2.data(), h_u2.size() * 4, hipMemcpyHostToDevice));
     float *d_u, *d_zeros;
     CK(hipMalloc(&d_u, h_u.size() * 4));
     CK(hipMemcpy(d_u, h_u.data(), h_u.size() * 4, hipMemcpyHostToDevice));
@@ -114,11 +139,13 @@ int main(int argc, char** argv)
         a.N = N; a.H = H; a.W = H; a.cout_blocks = cb; a.shuffle = mode == 2;
         a.zeros = d_zeros;
         if (which == 1 && use_wino) a.wpack = d_u;
+        if (which == 1 && variant == 2) a.wpack = d_u2;
         return a;
     };
     hipStream_t s;
     CK(hipStreamCreate(&s));
     auto run = [&](int which) {
+        if (which == 1 && variant == 2) return launch_conv3x3_f32_wreg(args(1), s);
         return which == 0 ? launch_conv3x3_f32(args(0), s) : (use_wino ? launch_conv3x3_f32_wino(args(1), s) : launch_conv3x3_f32(args(1), s));
     };
     for (int i = 0; i < 2; ++i) {
