@@ -37,7 +37,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f32_wreg_kernel(Conv3x3Args a,
     const float* zero = static_cast<const float*>(a.zeros) + kq * 4;
     // U pack: float4 units [nu 4][chunk 6][xi 4][s 6][lane 64]
 
-    f32x4 ub[4][6];                                      // U ring: slice (.., xi) lives in ub[xi]
+#ifndef WREG_RING
+#define WREG_RING 4
+#endif
+    constexpr int R = WREG_RING;                         // U ring depth in slices (divides 24), R - 1 ahead
+    f32x4 ub[R][6];                                      // slice q of a column lives in ub[q % R]
     // prefetch pointer: the slice three ahead of the one being multiplied; wave-uniform, so the loads take
     // the scalar-base form (base in SGPRs, lane * 16 in one VGPR) and advancing it costs no VALU
     const f32x4* const ubeg = static_cast<const f32x4*>(a.wpack);
@@ -51,9 +55,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f32_wreg_kernel(Conv3x3Args a,
     };
 
     // ring prologue: slices 0..2
-    load_u(0);
-    load_u(1);
-    load_u(2);
+#pragma unroll
+    for (int q = 0; q < R - 1; ++q) load_u(q);
 
     // tile geometry of an item
     struct Geo {
@@ -135,7 +138,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f32_wreg_kernel(Conv3x3Args a,
                 v[3] = dc[1] - dc[3];
 #pragma unroll
                 for (int xi = 0; xi < 4; ++xi) {
-                    load_u((xi + 3) & 3);
+                    const int q = chunk * 4 + xi;
+                    load_u((q + R - 1) % R);
                     if (xi == 0) {                        // next chunk's pixels, a chunk ahead
                         if (chunk == 5) {                 // ... of the next column, or of the next item
                             const bool last = nu == 3;
@@ -157,7 +161,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f32_wreg_kernel(Conv3x3Args a,
 #pragma unroll
                         for (int s = 0; s < 6; ++s) {
                             const f32x4 c = (chunk == 0 && j == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : m[xi][s];
-                            m[xi][s] = __builtin_amdgcn_mfma_f32_16x16x4f32(ub[xi][s][j], v[xi][j], c, 0, 0, 0);
+                            m[xi][s] = __builtin_amdgcn_mfma_f32_16x16x4f32(ub[q % R][s][j], v[xi][j], c, 0, 0, 0);
                         }
                     __builtin_amdgcn_sched_barrier(0);
                 }
