@@ -80,7 +80,6 @@ constexpr int SLAB = 6 * 96 * 16;                 // 9,216: one (tap, chunk) wei
 constexpr int NRING = 3;
 constexpr int BS_OFF = A_BYTES + NRING * SLAB;    // bias[4][96], slope[4][96] (fp32)
 constexpr int LDS_BYTES = BS_OFF + 2 * 4 * 96 * 4;   // 75,072 (two workgroups per CU)
-constexpr int A_ITEMS = HH * HWP * 6;             // 16-byte pieces per chunk (2,376)
 constexpr int MAX_WGS = 512;                      // persistent grid: 2 workgroups x 256 CUs
 
 struct Frags { bf16x8 a0, a1, b0, b1, b2; };
@@ -220,13 +219,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(Conv3x3Args a, int
         a_col |= (used ? 0u : 1u) << it | (cc == 0 ? 1u : 0u) << (10 + it) | (cc == HWP - 1 ? 1u : 0u) << (20 + it);
     }
     auto load_a = [&](const Item& t, int c) {
-#if defined(C3_NOMEM) && (C3_NOMEM & 1)      // development: always the same (L2-resident) tile
-        const __bf16* in = (const __bf16*)a.in;
-        const int x0 = 0, y0 = 4 + 0 * t.ty;
-#else
         const __bf16* in = (const __bf16*)a.in + (size_t)t.n * HW * HW * kC;
         const int x0 = t.tx * TW, y0 = t.ty * TH;
-#endif
         // rounds whose pixel is outside the image (or unused): zero
         unsigned bad = a_col;
         if (x0 == 0) bad |= a_col >> 10;
@@ -292,10 +286,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(Conv3x3Args a, int
     // has the matrix pipe to itself.  Speed only.
     if ((int)blockIdx.x >= ((int)gridDim.x >> 1) && gridDim.x >= 2 * 256) {
 #pragma unroll 1
-#ifndef C3_STAG
-#define C3_STAG 2
-#endif
-        for (int i = 0; i < C3_STAG; ++i) __builtin_amdgcn_s_sleep(100);
+        for (int i = 0; i < 2; ++i) __builtin_amdgcn_s_sleep(100);
     }
     store_a();
     wait_vm0();                                   // slabs 0, 1 (asm copies: not known to the compiler)
@@ -374,9 +365,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(Conv3x3Args a, int
                 }
             }
         };
-#ifdef C3_PRIO
-        __builtin_amdgcn_s_setprio(C3_PRIO);
-#endif
         run_chunk(std::integral_constant<int, 0>{});
         C3_STAMP(2);
         store_a();                                // every wave is past its last read of chunk 0
@@ -384,9 +372,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(Conv3x3Args a, int
         C3_STAMP(3);
         run_chunk(std::integral_constant<int, 1>{});
         C3_STAMP(4);
-#ifdef C3_PRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
 
         // the A tile is free (barrier of the last phase): fetch the next item's chunk 0 into the
         // staging registers now, its latency is covered by the epilogue arithmetic below
@@ -448,9 +433,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(Conv3x3Args a, int
                     swap32(x0d, y0d);
                     swap32(x1d, y1d);
                     const u32x4 ov = {x0d, x1d, y0d, y1d};
-#if defined(C3_NOMEM) && (C3_NOMEM & 2)      // development: no output stores (kept live)
-                    if (x0d == 0x12345678u)
-#endif
                     *(u32x4*)(out + (size_t)(32 * mt) * PXS + 32 * nt + 16 * P) = ov;
                 }
             }

@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_f32_wino_kernel(Conv3x3Args a,
                 // read ahead at xi = 3, s + 2 is staged (this nu's, the next nu's, or the next item's: nx is
                 // this item again after the last one, a harmless re-stage that keeps the vmcnt arithmetic)
                 const int buf = chunk >= 3 ? chunk - 3 : chunk;
-                const int bufn = buf == 2 ? 0 : buf + 1, bufs = bufn == 2 ? 0 : bufn + 1;
+                const int bufn = buf == 2 ? 0 : buf + 1;
                 // LDS addresses of this chunk's reads, formed here so that nothing but the reads
                 // themselves (address register + immediate offset) sits between the MFMAs below
                 const int u_lane = (kq * 96 + c16) * 16;

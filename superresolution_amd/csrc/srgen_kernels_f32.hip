@@ -34,7 +34,6 @@ __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >
 // tile (row padded to 28 => 252, the 28th weight is zero).  Reads NCHW, writes NHWC.
 // =========================================================================================
 constexpr int TS_ROWS = 12, TS_RS = 220;     // 4+8 halo rows; 72 cols * 3 ch = 216 (+4 pad)
-constexpr int TS_LDS_BYTES = TS_ROWS * TS_RS * 4;
 
 __global__ __launch_bounds__(256, 2) void stem_f32_kernel(StemArgs a)
 {
