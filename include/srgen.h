@@ -93,6 +93,19 @@ SRGEN_API int srgen_workspace_bytes(const srgen_handle* h, int n, int dtype, siz
 SRGEN_API int srgen_forward(srgen_handle* h, const void* x, void* y, void* workspace,
                   size_t workspace_bytes, int n, int dtype, void* stream);
 
+/* Replaces: Generator.forward in TRAIN mode, forward values only (Generator.py:74-80 after .train(), as at
+ * train.py:92,149,167 minus autograd): every BatchNorm2d (Generator.py:35,38,63) normalises with the batch
+ * mean and the biased batch variance over (n, 64, 64).  fp32.  x, y, workspace as for srgen_forward
+ * (srgen_workspace_bytes with SRGEN_F32).
+ *   bn_batch_stats : device, [2 * num_blocks + 1][2][96] floats, in module order (blocks.<i>.block.1,
+ *                    blocks.<i>.block.4, ..., mid.1): {batch mean, biased batch variance} of each BatchNorm.
+ *                    The running-statistics update (momentum 0.1, unbiased variance = biased * m / (m - 1),
+ *                    m = n * 4096) is the caller's: superresolution_amd.Generator applies it to its buffers.
+ * The first call after srgen_commit_weights packs and uploads the unfolded conv weights (synchronises once).
+ * The backward pass of the reference's training step is not built. */
+SRGEN_API int srgen_forward_train(srgen_handle* h, const void* x, void* y, void* workspace,
+                                  size_t workspace_bytes, int n, float* bn_batch_stats, void* stream);
+
 /* Layer taps for parity tests: same as srgen_forward, and additionally copies intermediate
  * activations out as NCHW fp32.  taps[i] is a device pointer or NULL (skip):
  *   0 stem (n,96,64,64)   1 block0   2 block7   3 ca8   4 block16   5 ca17   6 skip (x1+x3)

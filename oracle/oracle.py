@@ -285,3 +285,56 @@ def weighted_l1(sr, hr) -> float:
     sr, hr = np.asarray(sr, np.float64), np.asarray(hr, np.float64)
     weight = (np.asarray(hr, np.float32) > np.float32(0.01)).astype(np.float64) * 9 + 1
     return float((weight * np.abs(sr - hr)).mean())
+
+
+# ---- train-mode forward (batch-statistics BatchNorm): Generator.train()(x), train.py:92 ----
+
+def batchnorm_train(x, gamma, beta, running_mean, running_var, eps=1e-5, momentum=0.1):
+    """nn.BatchNorm2d in training mode (Generator.py:35,38,63): normalise with the batch mean and the
+    BIASED batch variance over (N, H, W); running statistics move by `momentum` towards the batch mean and
+    the UNBIASED batch variance.  fp64 statistics.  Returns (y, new_running_mean, new_running_var)."""
+    x = _f32(x)
+    n = x.shape[0] * x.shape[2] * x.shape[3]
+    x64 = x.astype(np.float64)
+    mean = x64.mean(axis=(0, 2, 3))
+    var = x64.var(axis=(0, 2, 3))
+    y = (x64 - mean[None, :, None, None]) / np.sqrt(var + eps)[None, :, None, None]
+    y = y * np.asarray(gamma, np.float64)[None, :, None, None] + np.asarray(beta, np.float64)[None, :, None, None]
+    new_mean = (1 - momentum) * np.asarray(running_mean, np.float64) + momentum * mean
+    new_var = (1 - momentum) * np.asarray(running_var, np.float64) + momentum * var * (n / max(n - 1, 1))
+    return y.astype(np.float32), new_mean.astype(np.float32), new_var.astype(np.float32)
+
+
+def generator_forward_train(sd: Dict[str, np.ndarray], x, num_blocks: int = 16):
+    """fp32 TRAIN-mode forward of the reference Generator.  Returns (y, {bn prefix: (running_mean,
+    running_var)}) with the statistics as they stand after this forward."""
+    sd = {k: np.asarray(v) for k, v in sd.items()}
+    x = _f32(x)
+    new_stats = {}
+
+    def bn(t, prefix):
+        y, m, v = batchnorm_train(t, *_bn_args(sd, prefix))
+        new_stats[prefix] = (m, v)
+        return y
+
+    x1 = prelu(conv2d(x, sd["input.0.weight"], sd["input.0.bias"]), sd["input.1.weight"])
+    cur = x1
+    idx = 0
+    for i in range(num_blocks):
+        p = f"blocks.{idx}.block"
+        t = prelu(bn(conv2d(cur, sd[p + ".0.weight"], sd[p + ".0.bias"]), p + ".1"), sd[p + ".2.weight"])
+        t = bn(conv2d(t, sd[p + ".3.weight"], sd[p + ".3.bias"]), p + ".4")
+        cur = axpy(cur, t, 0.1)
+        idx += 1
+        if i in (7, 15):
+            p = f"blocks.{idx}.fc"
+            cur, _ = channel_attention(cur, sd[p + ".0.weight"], sd[p + ".0.bias"],
+                                       sd[p + ".2.weight"], sd[p + ".2.bias"])
+            idx += 1
+    x3 = bn(conv2d(cur, sd["mid.0.weight"], sd["mid.0.bias"]), "mid.1")
+    s = axpy(x1, x3, 1.0)
+    u = prelu(pixel_shuffle(conv2d(s, sd["upsample.conv.weight"], sd["upsample.conv.bias"]), 2),
+              sd["upsample.act.weight"])
+    o = prelu(conv2d(u, sd["output.0.weight"], sd["output.0.bias"]), sd["output.1.weight"])
+    o = conv2d(o, sd["output.2.weight"], sd["output.2.bias"])
+    return crop(o, 125, 125), new_stats

@@ -61,6 +61,8 @@ def lib() -> ctypes.CDLL:
     L.srgen_commit_weights.argtypes = [vp, vp]
     L.srgen_workspace_bytes.argtypes = [vp, i, i, ctypes.POINTER(sz)]
     L.srgen_forward.argtypes = [vp, vp, vp, vp, sz, i, i, vp]
+    L.srgen_forward_train.argtypes = [vp, vp, vp, vp, sz, i, vp, vp]
+    L.srgen_forward_train.restype = i
     L.srgen_forward_taps.argtypes = [vp, vp, vp, vp, sz, i, i, ctypes.POINTER(vp), vp]
     L.srgen_forward_profile.argtypes = [vp, vp, vp, vp, sz, i, i, vp, ctypes.POINTER(ctypes.c_float),
                                         ctypes.POINTER(ctypes.c_int)]

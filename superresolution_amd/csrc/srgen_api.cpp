@@ -80,6 +80,15 @@ struct srgen_handle {
     size_t zeros = 0;              // kWinoZeroBytes of zeros in the blob (Winograd halo padding rows)
     bool f32_wino = true;          // fp32 3x3 convs: Winograd F(2x2,3x3) kernel (default) or the direct one
     bool f32_wreg = false;         // experimental: the register-only Winograd kernel on the trunk convs it covers
+    // train-mode forward (srgen_forward_train): unfolded conv weights + BatchNorm affine parameters, built
+    // lazily on the first train-mode call after a commit
+    char* tblob = nullptr;         // device
+    size_t tblob_bytes = 0;
+    bool train_ready = false;
+    std::vector<ConvDev> t_conv1, t_conv2;
+    ConvDev t_mid;
+    size_t t_affine = 0;           // [num_bn][2][96]: gamma, beta in module order
+    size_t t_ones = 0;             // [96] ones: identity PReLU slope for the raw conv launches
 };
 
 namespace {
@@ -366,7 +375,7 @@ struct Prof {
 };
 
 struct Workspace {
-    size_t x1, a, b, t, u, v, pool, scale[2], total;
+    size_t x1, a, b, t, u, v, pool, scale[2], bn, total;
 };
 
 Workspace plan_workspace(int n, int dtype)
@@ -384,6 +393,7 @@ Workspace plan_workspace(int n, int dtype)
     w.pool = off; off += align256((size_t)n * 16 * kC * 4);
     w.scale[0] = off; off += align256((size_t)n * kC * 4);
     w.scale[1] = off; off += align256((size_t)n * kC * 4);
+    w.bn = off; off += align256(bn_scratch_bytes());
     w.total = off;
     return w;
 }
@@ -430,6 +440,7 @@ int srgen_destroy(srgen_handle* h)
 {
     if (!h) return SRGEN_OK;
     if (h->blob) (void)hipFree(h->blob);
+    if (h->tblob) (void)hipFree(h->tblob);
     delete h;
     return SRGEN_OK;
 }
@@ -532,6 +543,7 @@ int srgen_commit_weights(srgen_handle* h, void* stream)
     HIP_TRY(hipMemcpyAsync(h->blob, blob.bytes.data(), blob.bytes.size(), hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));                 // host staging buffer dies with this scope
     h->committed = true;
+    h->train_ready = false;
     return SRGEN_OK;
 }
 
@@ -544,8 +556,59 @@ int srgen_workspace_bytes(const srgen_handle* h, int n, int dtype, size_t* bytes
     return SRGEN_OK;
 }
 
+// Unfolded conv weights and BatchNorm affine parameters for the train-mode forward.
+static int prepare_train(srgen_handle* h, hipStream_t s)
+{
+    if (h->train_ready) return SRGEN_OK;
+    Blob blob;
+    const std::vector<int> id96 = identity_perm(96);
+    auto raw = [&](const std::string& key) {
+        Folded f = fold(h, key, "", 1.0, 96, 96, 3);             // no BatchNorm folded in, scale 1
+        ConvDev d;
+        d.w_wino = blob.put_f32(pack3x3_wino_f32(f, 1, id96));
+        d.bias = blob.put_f32(f.b);
+        return d;
+    };
+    std::vector<float> affine;
+    auto bn = [&](const std::string& key) {
+        const std::vector<float>& g = h->tensors.at(key + ".weight");
+        const std::vector<float>& b = h->tensors.at(key + ".bias");
+        affine.insert(affine.end(), g.begin(), g.end());
+        affine.insert(affine.end(), b.begin(), b.end());
+    };
+    h->t_conv1.clear();
+    h->t_conv2.clear();
+    for (int i = 0; i < h->cfg.num_blocks; ++i) {
+        const std::string p = "blocks." + std::to_string(seq_index(i)) + ".block";
+        h->t_conv1.push_back(raw(p + ".0"));
+        bn(p + ".1");
+        h->t_conv2.push_back(raw(p + ".3"));
+        bn(p + ".4");
+    }
+    h->t_mid = raw("mid.0");
+    bn("mid.1");
+    h->t_affine = blob.put_f32(affine);
+    h->t_ones = blob.put_f32(std::vector<float>(96, 1.f));
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (h->tblob_bytes < blob.bytes.size()) {
+        if (h->tblob) HIP_TRY(hipFree(h->tblob));
+        h->tblob = nullptr;
+        h->tblob_bytes = 0;
+        HIP_TRY(hipMalloc((void**)&h->tblob, blob.bytes.size()));
+        h->tblob_bytes = blob.bytes.size();
+    }
+    HIP_TRY(hipMemcpyAsync(h->tblob, blob.bytes.data(), blob.bytes.size(), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    h->train_ready = true;
+    return SRGEN_OK;
+}
+
+// bn_stats != nullptr selects the train-mode forward (fp32): every conv that is followed by a BatchNorm runs
+// unfolded, then the batch statistics and the normalisation (launch_bn_train); bn_stats receives
+// [2 * num_blocks + 1][2][96] = {batch mean, biased batch variance} in module order.
 static int run_forward(srgen_handle* h, const void* x, void* y, void* workspace, size_t workspace_bytes,
-                       int n, int dtype, void* const* taps, void* stream, Prof* prof)
+                       int n, int dtype, void* const* taps, void* stream, Prof* prof, float* bn_stats = nullptr)
 {
     if (!h) return fail(SRGEN_E_INVALID, "handle is NULL");
     if (!h->committed) return fail(SRGEN_E_STATE, "srgen_forward before srgen_commit_weights");
@@ -607,6 +670,29 @@ static int run_forward(srgen_handle* h, const void* x, void* y, void* workspace,
     void* t = W + ws.t;
     float* pool = (float*)(W + ws.pool);
 
+    const bool train = bn_stats != nullptr;
+    const char* TB = h->tblob;
+    int bn_index = 0;
+    // conv (unfolded weights, bias, no activation) -> batch statistics -> normalise in place (+ PReLU | + residual)
+    auto conv_bn = [&](const ConvDev& d, const void* in, void* out, const float* slope, const void* res,
+                       float res_factor) -> int {
+        Conv3x3Args a;
+        a.in = in; a.out = out;
+        a.wpack = TB + d.w_wino;
+        a.zeros = B + h->zeros;
+        a.bias = (const float*)(TB + d.bias);
+        a.slope = (const float*)(TB + h->t_ones);                // identity PReLU: the raw conv output
+        a.res = nullptr; a.pool_partial = nullptr;
+        a.N = n; a.H = kLR; a.W = kLR;
+        a.cout_blocks = 1; a.shuffle = 0;
+        HIP_TRY(launch_conv3x3_f32_wino(a, s));
+        const float* gb = (const float*)(TB + h->t_affine) + (size_t)bn_index * 192;
+        HIP_TRY(launch_bn_train((float*)out, (size_t)n * kLR * kLR, gb, gb + 96, slope, (const float*)res,
+                                res_factor, W + ws.bn, bn_stats + (size_t)bn_index * 192, s));
+        ++bn_index;
+        return SRGEN_OK;
+    };
+
     {   // x1 = input(x)                                                   Generator.py:75
         StemArgs a{x, x1, B + (bf ? h->stem.w_bf16 : h->stem.w_f32), F(h->stem.bias), F(h->stem.slope), n};
         HIP_TRY(tick(SRGEN_K_STEM));
@@ -620,8 +706,14 @@ static int run_forward(srgen_handle* h, const void* x, void* y, void* workspace,
         const bool has_ca = (i == 7 || i == 15);
         void* nxt = bufs[flip];
         flip ^= 1;
-        HIP_TRY(conv(h->conv1[i], cur, t, nullptr, nullptr, kLR, 0));
-        HIP_TRY(conv(h->conv2[i], t, nxt, cur, has_ca ? pool : nullptr, kLR, 0));
+        if (train) {                                    // Generator.py:34-38,42 with batch statistics
+            if (int rc = conv_bn(h->t_conv1[i], cur, t, F(h->conv1[i].slope), nullptr, 0.f)) return rc;
+            if (int rc = conv_bn(h->t_conv2[i], t, nxt, nullptr, cur, 0.1f)) return rc;
+            if (has_ca) HIP_TRY(launch_pool_partial((const float*)nxt, n, kLR * kLR, 16, pool, s));
+        } else {
+            HIP_TRY(conv(h->conv1[i], cur, t, nullptr, nullptr, kLR, 0));
+            HIP_TRY(conv(h->conv2[i], t, nxt, cur, has_ca ? pool : nullptr, kLR, 0));
+        }
         cur = nxt;
         const int idx = seq_index(i);
         if (idx == 0) HIP_TRY(tap(1, cur, kLR * kLR));
@@ -641,7 +733,11 @@ static int run_forward(srgen_handle* h, const void* x, void* y, void* workspace,
         }
     }
     void* m = bufs[flip];                               // x1 + mid(x2)     Generator.py:77-78
-    HIP_TRY(conv(h->mid, cur, m, x1, nullptr, kLR, 0));
+    if (train) {
+        if (int rc = conv_bn(h->t_mid, cur, m, nullptr, x1, 1.f)) return rc;
+    } else {
+        HIP_TRY(conv(h->mid, cur, m, x1, nullptr, kLR, 0));
+    }
     HIP_TRY(tap(6, m, kLR * kLR));
     void* u = W + ws.u;                                 // upsample         Generator.py:78, 4-12
     HIP_TRY(conv(h->up, m, u, nullptr, nullptr, kLR, 1));
@@ -693,6 +789,16 @@ int srgen_forward(srgen_handle* h, const void* x, void* y, void* workspace, size
                   int dtype, void* stream)
 {
     return srgen_forward_taps(h, x, y, workspace, workspace_bytes, n, dtype, nullptr, stream);
+}
+
+int srgen_forward_train(srgen_handle* h, const void* x, void* y, void* workspace, size_t workspace_bytes, int n,
+                        float* bn_batch_stats, void* stream)
+{
+    if (!h) return fail(SRGEN_E_INVALID, "handle is NULL");
+    if (!h->committed) return fail(SRGEN_E_STATE, "srgen_forward_train before srgen_commit_weights");
+    if (!bn_batch_stats) return fail(SRGEN_E_INVALID, "bn_batch_stats is NULL");
+    if (int rc = prepare_train(h, (hipStream_t)stream)) return rc;
+    return run_forward(h, x, y, workspace, workspace_bytes, n, SRGEN_F32, nullptr, stream, nullptr, bn_batch_stats);
 }
 
 int srgen_bilinear_resize(const float* x, float* y, int planes, int hgt, int wid, int oh, int ow, void* stream)

@@ -129,6 +129,15 @@ hipError_t launch_disc_tail(const DiscTailArgs& a, hipStream_t s);
 hipError_t launch_ragan_loss(const float* real, const float* fake, size_t n_real, size_t n_fake,
                              float real_label, float fake_label, float* out2, hipStream_t s);
 
+// ---- train-mode BatchNorm over an NHWC (npix, 96) fp32 tensor, in place (srgen_kernels_misc.hip) ------------
+// t <- slope ? PReLU(bn(t)) : bn(t);  then, with res: t <- res + res_factor * t.  bn uses the batch mean and
+// the biased batch variance (eps 1e-5); batch_stats receives {mean[96], biased var[96]}.
+constexpr int kBnBlocks = 512;
+size_t bn_scratch_bytes();
+hipError_t launch_bn_train(float* t, size_t npix, const float* gamma, const float* beta, const float* slope,
+                           const float* res, float res_factor, void* scratch, float* batch_stats, hipStream_t s);
+hipError_t launch_pool_partial(const float* t, int n, int hw, int parts, float* pool_partial, hipStream_t s);
+
 // ---- packed-weight geometry shared by the packers (host) and the kernels ---------------
 // fp32 3x3: float4 units  [cout_block][tap 9][ci4 24][co 96] -> 4 consecutive ci
 constexpr size_t kConv3x3F32Floats = (size_t)9 * 96 * 96;             // per cout block

@@ -270,4 +270,134 @@ hipError_t launch_metrics(const float* sr, const float* hr, int n, int c, int h,
                      : launch_metrics_n<3>(sr, hr, n, c, h, w, out, scratch, s);
 }
 
+// ---- train-mode BatchNorm (nn.BatchNorm2d in .train(), Generator.py:35,38,63) over NHWC (P, 96) fp32 ------
+// Three HBM-bound passes around the (unfolded) conv: bn_stats (per-channel sum / sum of squares: fp32 inside a
+// thread's ~100-pixel run, fp64 across threads and workgroups), bn_final (one workgroup: mean, biased variance,
+// the fused scale / shift of the normalisation, and the batch statistics for the caller's running-statistics
+// update), bn_apply (normalise in place + PReLU, or residual + factor * normalised).
+constexpr int BN_THREADS = 240;                // 10 pixel rows x 24 float4 channel groups
+
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ t, size_t npix, double* partial)
+{
+    __shared__ double red[10][2][96];
+    const int tid = threadIdx.x;
+    if (tid < BN_THREADS) {
+        const int c4 = tid % 24, row = tid / 24;
+        const size_t per = (npix + gridDim.x - 1) / gridDim.x;
+        const size_t p0 = (size_t)blockIdx.x * per, p1 = p0 + per < npix ? p0 + per : npix;
+        float sx[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
+        for (size_t p = p0 + row; p < p1; p += 10) {
+            const float4 v = *reinterpret_cast<const float4*>(t + p * 96 + c4 * 4);
+            sx[0] += v.x; sx[1] += v.y; sx[2] += v.z; sx[3] += v.w;
+            sq[0] += v.x * v.x; sq[1] += v.y * v.y; sq[2] += v.z * v.z; sq[3] += v.w * v.w;
+        }
+        for (int e = 0; e < 4; ++e) {
+            red[row][0][c4 * 4 + e] = (double)sx[e];
+            red[row][1][c4 * 4 + e] = (double)sq[e];
+        }
+    }
+    __syncthreads();
+    if (tid < 192) {
+        const int k = tid / 96, c = tid % 96;
+        double a = 0.0;
+        for (int r = 0; r < 10; ++r) a += red[r][k][c];
+        partial[(size_t)blockIdx.x * 192 + tid] = a;
+    }
+}
+
+__global__ __launch_bounds__(192) void bn_final_kernel(const double* partial, int nb, double npix,
+                                                       const float* gamma, const float* beta, float eps,
+                                                       float* scale_shift, float* batch_stats)
+{
+    __shared__ double tot[192];
+    double a = 0.0;
+    for (int b = 0; b < nb; ++b) a += partial[(size_t)b * 192 + threadIdx.x];
+    tot[threadIdx.x] = a;
+    __syncthreads();
+    if (threadIdx.x < 96) {
+        const int c = threadIdx.x;
+        const double mean = tot[c] / npix;
+        double var = tot[96 + c] / npix - mean * mean;          // biased (what the normalisation uses)
+        var = var > 0.0 ? var : 0.0;
+        const double sc = (double)gamma[c] / sqrt(var + (double)eps);
+        scale_shift[c] = (float)sc;
+        scale_shift[96 + c] = (float)((double)beta[c] - mean * sc);
+        batch_stats[c] = (float)mean;
+        batch_stats[96 + c] = (float)var;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(float* t, const float* __restrict__ scale_shift,
+                                                       const float* __restrict__ slope, const float* __restrict__ res,
+                                                       float res_factor, size_t n4)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % 24) * 4;
+        float4 v = *reinterpret_cast<const float4*>(t + i * 4);
+        const float4 sc = *reinterpret_cast<const float4*>(scale_shift + c);
+        const float4 sh = *reinterpret_cast<const float4*>(scale_shift + 96 + c);
+        v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+        if (slope) {                                             // PReLU(ch), Generator.py:36
+            const float4 sl = *reinterpret_cast<const float4*>(slope + c);
+            v.x = v.x >= 0.f ? v.x : v.x * sl.x; v.y = v.y >= 0.f ? v.y : v.y * sl.y;
+            v.z = v.z >= 0.f ? v.z : v.z * sl.z; v.w = v.w >= 0.f ? v.w : v.w * sl.w;
+        }
+        if (res) {                                               // x + 0.1 * block(x) (:42) / x1 + mid(x2) (:78)
+            const float4 r = *reinterpret_cast<const float4*>(res + i * 4);
+            v.x = fmaf(res_factor, v.x, r.x); v.y = fmaf(res_factor, v.y, r.y);
+            v.z = fmaf(res_factor, v.z, r.z); v.w = fmaf(res_factor, v.w, r.w);
+        }
+        *reinterpret_cast<float4*>(t + i * 4) = v;
+    }
+}
+
+// per-image channel sums in the pool_partial layout of the conv epilogue: [N][parts][96], part = hw/parts pixels
+__global__ __launch_bounds__(256) void pool_partial_kernel(const float* __restrict__ t, int hw, int parts,
+                                                           float* pool_partial)
+{
+    __shared__ float red[10][96];
+    const int tid = threadIdx.x;
+    const int per = hw / parts;
+    const size_t p0 = (size_t)blockIdx.x * per;                  // blockIdx.x = image * parts + part
+    if (tid < BN_THREADS) {
+        const int c4 = tid % 24, row = tid / 24;
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int p = row; p < per; p += 10) {
+            const float4 v = *reinterpret_cast<const float4*>(t + (p0 + p) * 96 + c4 * 4);
+            s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+        }
+        for (int e = 0; e < 4; ++e) red[row][c4 * 4 + e] = s[e];
+    }
+    __syncthreads();
+    if (tid < 96) {
+        float a = 0.f;
+        for (int r = 0; r < 10; ++r) a += red[r][tid];
+        pool_partial[(size_t)blockIdx.x * 96 + tid] = a;
+    }
+}
+
+size_t bn_scratch_bytes() { return (size_t)kBnBlocks * 192 * sizeof(double) + 2 * 96 * sizeof(float); }
+
+hipError_t launch_bn_train(float* t, size_t npix, const float* gamma, const float* beta, const float* slope,
+                           const float* res, float res_factor, void* scratch, float* batch_stats, hipStream_t s)
+{
+    double* partial = static_cast<double*>(scratch);
+    float* ss = reinterpret_cast<float*>(partial + (size_t)kBnBlocks * 192);
+    const int nb = npix < (size_t)kBnBlocks * 10 ? (int)((npix + 9) / 10) : kBnBlocks;
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(nb), dim3(256), 0, s, t, npix, partial);
+    hipLaunchKernelGGL(bn_final_kernel, dim3(1), dim3(192), 0, s, partial, nb, (double)npix, gamma, beta, 1e-5f, ss,
+                       batch_stats);
+    const size_t n4 = npix * 24;
+    const size_t want = (n4 + 255) / 256;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)(want < 16384 ? want : 16384)), dim3(256), 0, s, t, ss, slope,
+                       res, res_factor, n4);
+    return hipGetLastError();
+}
+
+hipError_t launch_pool_partial(const float* t, int n, int hw, int parts, float* pool_partial, hipStream_t s)
+{
+    hipLaunchKernelGGL(pool_partial_kernel, dim3((unsigned)(n * parts)), dim3(256), 0, s, t, hw, parts, pool_partial);
+    return hipGetLastError();
+}
+
 }  // namespace srgen

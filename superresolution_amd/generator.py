@@ -85,9 +85,12 @@ class Generator(nn.Module):
 
     # ---- HIP handle / weights ----------------------------------------------------------
     def _signature(self) -> Tuple:
-        return tuple((t.data_ptr(), t._version) for t in self.state_dict(keep_vars=True).values())
+        """(parameters, buffers): the train-mode forward reads no BatchNorm running statistics, so its own
+        updates of those buffers must not force a re-upload before the next train-mode call."""
+        return (tuple((t.data_ptr(), t._version) for t in self.parameters()),
+                tuple((t.data_ptr(), t._version) for t in self.buffers()))
 
-    def _handle(self, device: torch.device) -> int:
+    def _handle(self, device: torch.device, train: bool = False) -> int:
         idx = device.index if device.index is not None else torch.cuda.current_device()
         L = _lib.lib()
         if idx not in self._handles:
@@ -98,7 +101,8 @@ class Generator(nn.Module):
             self._handles[idx] = h.value
         h = self._handles[idx]
         sig = self._signature()
-        if self._weights_sig.get(idx) != sig:
+        have = self._weights_sig.get(idx)
+        if have != sig and not (train and have is not None and have[0] == sig[0]):
             self._upload(h, idx)
             self._weights_sig[idx] = sig
         return h
@@ -131,10 +135,12 @@ class Generator(nn.Module):
 
     # ---- forward -------------------------------------------------------------------------
     def _prepare(self, x: torch.Tensor):
-        if self.training:
+        if self.training and torch.is_grad_enabled() and (
+                x.requires_grad or any(p.requires_grad for p in self.parameters())):
             raise NotImplementedError(
-                "Generator.forward in train mode (batch-stat BatchNorm + autograd; train.py:92,149,167) is "
-                "not built: call .eval() first. There is no eager fallback.")
+                "Generator.forward in train mode under autograd (train.py:92,149,167): the backward pass is not "
+                "built. Train-mode forward VALUES (batch-statistics BatchNorm, running-statistics update) run "
+                "under torch.no_grad(); for inference call .eval(). There is no eager fallback.")
         if not isinstance(x, torch.Tensor) or x.dim() != 4:
             raise RuntimeError(f"Expected 4D (N, {self.in_ch}, 64, 64) input, got {tuple(getattr(x, 'shape', ()))}")
         if x.shape[1] != self.in_ch:
@@ -158,7 +164,42 @@ class Generator(nn.Module):
         return x.detach().to(dt).contiguous(), (_lib.SRGEN_BF16 if bf16 else _lib.SRGEN_F32), dt
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.training:
+            return self._run_train(x)
         return self._run(x, None)
+
+    def _bn_modules(self):
+        """The BatchNorm2d layers in module order (= the order of srgen_forward_train's bn_batch_stats)."""
+        return [m for m in self.modules() if isinstance(m, nn.BatchNorm2d)]
+
+    def _run_train(self, x: torch.Tensor) -> torch.Tensor:
+        """Train-mode forward values (``Generator.train()(x)`` without autograd): batch-statistics BatchNorm
+        in the kernels, then the running-statistics update of ``nn.BatchNorm2d`` (momentum 0.1, unbiased
+        variance, ``num_batches_tracked += 1``) on this module's buffers.  fp32."""
+        xc, code, dt = self._prepare(x)
+        if code != _lib.SRGEN_F32:
+            raise RuntimeError("the train-mode forward is fp32 only (bf16 input or autocast is not built)")
+        n, idx = xc.shape[0], xc.device.index
+        y = torch.empty((n, self.in_ch, self.OUT, self.OUT), dtype=dt, device=xc.device)
+        if n == 0:
+            raise ValueError("Expected more than 1 value per channel when training, got an empty batch")
+        h = self._handle(xc.device, train=True)
+        ws = self._ws(h, idx, n, code)
+        bns = self._bn_modules()
+        stats = torch.empty((len(bns), 2, self.base_ch), dtype=torch.float32, device=xc.device)
+        with torch.cuda.device(idx):
+            _lib.check(_lib.lib().srgen_forward_train(h, xc.data_ptr(), y.data_ptr(), ws.data_ptr(), ws.numel(), n,
+                                                      stats.data_ptr(), torch.cuda.current_stream(idx).cuda_stream))
+        m = n * self.LR * self.LR
+        with torch.no_grad():
+            for k, bn in enumerate(bns):
+                if not bn.track_running_stats or bn.running_mean is None:
+                    continue
+                mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
+                bn.running_mean.mul_(1 - mom).add_(stats[k, 0], alpha=mom)
+                bn.running_var.mul_(1 - mom).add_(stats[k, 1], alpha=mom * m / max(m - 1, 1))
+                bn.num_batches_tracked += 1
+        return y
 
     def forward_taps(self, x: torch.Tensor):
         """(y, {tap name: NCHW fp32 tensor}) -- layer taps for parity tests (srgen_forward_taps)."""

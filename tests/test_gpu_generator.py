@@ -198,3 +198,60 @@ def test_reload_weights_changes_output(golden_inputs):
     y2 = g(x)
     assert not torch.equal(y0, y1)
     assert torch.equal(y0, y2)
+
+
+# ---- train-mode forward values (forward part) ---------------------------------------------
+def _train_batch(seed):
+    from superresolution_amd import weights as W
+    return np.concatenate([W.synthetic_lr_batch(3, seed, "dense"), W.synthetic_lr_batch(1, seed, "sparse")], 0)
+
+
+def test_train_mode_forward_vs_reference_golden():
+    """Generator.train()(x) under no_grad against tests/golden/generator_train.npz (the real reference run
+    twice in train mode, make_golden_train.py): outputs, and the running statistics / num_batches_tracked
+    of all 33 BatchNorm layers after each of two consecutive forwards."""
+    import os
+    from conftest import GOLDEN
+    from superresolution_amd import Generator, weights as W
+    gt = np.load(os.path.join(GOLDEN, "generator_train.npz"))
+    g = Generator()
+    g.load_state_dict(W.synthetic_state_dict(0))
+    g = g.cuda().train()
+    keys = [str(k) for k in gt["bn_keys"]]
+    with pytest.raises(NotImplementedError, match="no_grad"):
+        g(torch.from_numpy(_train_batch(2)).cuda())             # autograd on: backward is not built
+    for step, seed in ((1, 2), (2, 3)):
+        with torch.no_grad():
+            y = g(torch.from_numpy(_train_batch(seed)).cuda())
+        err = max_rel(y.cpu().numpy(), gt[f"y{step}"])
+        sd = g.state_dict()
+        em = max(np.abs(sd[k + ".running_mean"].cpu().numpy() - gt[f"mean{step}"][i]).max() for i, k in enumerate(keys))
+        ev = max(max_rel(sd[k + ".running_var"].cpu().numpy(), gt[f"var{step}"][i]) for i, k in enumerate(keys))
+        print(f"train forward {step}: y {err:.3e}, running_mean abs {em:.3e}, running_var rel {ev:.3e}")
+        assert err <= FP32_TOL and em <= 1e-5 and ev <= 1e-5
+    assert [int(sd[k + ".num_batches_tracked"]) for k in keys] == [int(v) for v in gt["nbt"]]
+    # back to eval: the folded weights are rebuilt from the UPDATED running statistics
+    x = torch.from_numpy(_train_batch(2)).cuda()
+    with torch.no_grad():
+        y_eval = g.eval()(x)
+    g2 = Generator()
+    g2.load_state_dict({k: v.cpu() for k, v in g.state_dict().items()})
+    assert torch.equal(y_eval, g2.cuda().eval()(x))
+
+
+def test_train_mode_forward_vs_cpu_oracle_other_shapes():
+    from oracle import oracle as O
+    from superresolution_amd import Generator, weights as W
+    for n, seed in ((1, 4), (7, 5)):
+        g = Generator()
+        g.load_state_dict(W.synthetic_state_dict(7))
+        g = g.cuda().train()
+        x = W.synthetic_lr_batch(n, seed=seed, kind="dense")
+        ref, stats = O.generator_forward_train(W.synthetic_state_dict_numpy(7), x)
+        with torch.no_grad():
+            y = g(torch.from_numpy(x).cuda())
+        assert max_rel(y.cpu().numpy(), ref) <= FP32_TOL, n
+        sd = g.state_dict()
+        for k, (m, v) in stats.items():
+            assert np.abs(sd[k + ".running_mean"].cpu().numpy() - m).max() <= 1e-5, (n, k)
+            assert max_rel(sd[k + ".running_var"].cpu().numpy(), v) <= 1e-5, (n, k)

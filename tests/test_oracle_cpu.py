@@ -119,3 +119,21 @@ def test_oracle_ops_against_torch_small():
     assert np.array_equal(O.crop(x, 3, 4), x[:, :, :3, :4])
     # empty batch
     assert O.conv2d(x[:0], w, b).shape == (0, 4, 7, 9)
+
+
+def test_oracle_train_mode_forward_matches_reference_golden():
+    """oracle.generator_forward_train (batch-statistics BatchNorm) against the fixture made by running the
+    real reference in train mode (tests/golden/make_golden_train.py): output and the running statistics of
+    all 33 BatchNorm layers after one forward."""
+    import os
+    from conftest import GOLDEN
+    from oracle import oracle as O
+    from superresolution_amd import weights as W
+    gt = np.load(os.path.join(GOLDEN, "generator_train.npz"))
+    x = np.concatenate([W.synthetic_lr_batch(3, 2, "dense"), W.synthetic_lr_batch(1, 2, "sparse")], 0)
+    y, stats = O.generator_forward_train(W.synthetic_state_dict_numpy(0), x)
+    assert max_rel(y, gt["y1"]) <= 1e-5
+    for i, k in enumerate(str(k) for k in gt["bn_keys"]):
+        assert np.abs(stats[k][0] - gt["mean1"][i]).max() <= 1e-6, k
+        assert max_rel(stats[k][1], gt["var1"][i]) <= 1e-6, k
+    assert len(stats) == 33
