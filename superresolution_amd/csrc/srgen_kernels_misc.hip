@@ -305,14 +305,21 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
     }
 }
 
-__global__ __launch_bounds__(192) void bn_final_kernel(const double* partial, int nb, double npix,
+__global__ __launch_bounds__(768) void bn_final_kernel(const double* partial, int nb, double npix,
                                                        const float* gamma, const float* beta, float eps,
                                                        float* scale_shift, float* batch_stats)
 {
+    __shared__ double part[4][192];
     __shared__ double tot[192];
-    double a = 0.0;
-    for (int b = 0; b < nb; ++b) a += partial[(size_t)b * 192 + threadIdx.x];
-    tot[threadIdx.x] = a;
+    {   // 4 threads per column, fixed order
+        const int col = threadIdx.x % 192, q = threadIdx.x / 192;
+        double a = 0.0;
+        for (int b = q; b < nb; b += 4) a += partial[(size_t)b * 192 + col];
+        part[q][col] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x < 192) tot[threadIdx.x] = (part[0][threadIdx.x] + part[1][threadIdx.x]) +
+                                              (part[2][threadIdx.x] + part[3][threadIdx.x]);
     __syncthreads();
     if (threadIdx.x < 96) {
         const int c = threadIdx.x;
@@ -385,7 +392,7 @@ hipError_t launch_bn_train(float* t, size_t npix, const float* gamma, const floa
     float* ss = reinterpret_cast<float*>(partial + (size_t)kBnBlocks * 192);
     const int nb = npix < (size_t)kBnBlocks * 10 ? (int)((npix + 9) / 10) : kBnBlocks;
     hipLaunchKernelGGL(bn_stats_kernel, dim3(nb), dim3(256), 0, s, t, npix, partial);
-    hipLaunchKernelGGL(bn_final_kernel, dim3(1), dim3(192), 0, s, partial, nb, (double)npix, gamma, beta, 1e-5f, ss,
+    hipLaunchKernelGGL(bn_final_kernel, dim3(1), dim3(768), 0, s, partial, nb, (double)npix, gamma, beta, 1e-5f, ss,
                        batch_stats);
     const size_t n4 = npix * 24;
     const size_t want = (n4 + 255) / 256;

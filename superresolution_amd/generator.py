@@ -191,14 +191,18 @@ class Generator(nn.Module):
             _lib.check(_lib.lib().srgen_forward_train(h, xc.data_ptr(), y.data_ptr(), ws.data_ptr(), ws.numel(), n,
                                                       stats.data_ptr(), torch.cuda.current_stream(idx).cuda_stream))
         m = n * self.LR * self.LR
-        with torch.no_grad():
-            for k, bn in enumerate(bns):
-                if not bn.track_running_stats or bn.running_mean is None:
-                    continue
-                mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
-                bn.running_mean.mul_(1 - mom).add_(stats[k, 0], alpha=mom)
-                bn.running_var.mul_(1 - mom).add_(stats[k, 1], alpha=mom * m / max(m - 1, 1))
-                bn.num_batches_tracked += 1
+        with torch.no_grad():                              # nn.BatchNorm2d's update, batched over the layers
+            live = [(k, bn) for k, bn in enumerate(bns) if bn.track_running_stats and bn.running_mean is not None]
+            mom = 0.1                                       # Generator.py builds every BatchNorm2d with the default
+            for k, bn in live:
+                if bn.momentum != mom:
+                    raise NotImplementedError(f"BatchNorm2d momentum {bn.momentum}: only the default 0.1 is built")
+            means, varis = [bn.running_mean for _, bn in live], [bn.running_var for _, bn in live]
+            torch._foreach_mul_(means, 1 - mom)
+            torch._foreach_add_(means, [stats[k, 0] for k, _ in live], alpha=mom)
+            torch._foreach_mul_(varis, 1 - mom)
+            torch._foreach_add_(varis, [stats[k, 1] for k, _ in live], alpha=mom * m / max(m - 1, 1))
+            torch._foreach_add_([bn.num_batches_tracked for _, bn in live], 1)
         return y
 
     def forward_taps(self, x: torch.Tensor):
