@@ -122,3 +122,17 @@ def test_autograd_calls_raise_and_weight_reload(disc):
         bad = dict(sd0)
         bad["head.2.weight"] = torch.zeros(1, 128, 3, 3, device="cuda")
         disc.load_state_dict(bad)
+
+
+def test_full_batch_256_every_slot_matches_golden(disc, gd, golden):
+    """The reference's GAN-phase batch (config.py:8): the two golden sr images repeated 128 times make the
+    persistent workgroups of every conv layer walk many tiles; every copy must reproduce the reference's
+    logits, and all copies must be bit-identical to each other."""
+    sr = torch.from_numpy(np.tile(golden["y_dense_sparse"], (128, 1, 1, 1))).cuda()
+    with torch.no_grad():
+        y = disc(sr)
+    assert y.shape == (256, 1, 8, 8)
+    assert torch.equal(y[0::2], y[0:1].expand(128, -1, -1, -1))
+    assert torch.equal(y[1::2], y[1:2].expand(128, -1, -1, -1))
+    assert max_rel(y[:2].cpu().numpy(), gd["d_fake"]) <= FP32_TOL
+    assert max_rel(y[254:].cpu().numpy(), gd["d_fake"]) <= FP32_TOL
