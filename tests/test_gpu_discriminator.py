@@ -136,3 +136,33 @@ def test_full_batch_256_every_slot_matches_golden(disc, gd, golden):
     assert torch.equal(y[1::2], y[1:2].expand(128, -1, -1, -1))
     assert max_rel(y[:2].cpu().numpy(), gd["d_fake"]) <= FP32_TOL
     assert max_rel(y[254:].cpu().numpy(), gd["d_fake"]) <= FP32_TOL
+
+
+def test_gan_phase_forward_values_end_to_end(disc, golden_inputs):
+    """The forward values of one GAN-phase batch (train.py:149-172) composed from the HIP pieces -- generator,
+    discriminator on hr and on the generator's output, RaGAN losses, weighted_l1 and SSIM -- against the same
+    chain composed from the CPU oracle."""
+    from oracle import oracle as O
+    from superresolution_amd import Generator, RelativisticAverageLoss, pixel_losses, weights as W
+    sd = W.synthetic_state_dict(0)
+    g = Generator()
+    g.load_state_dict(sd)
+    g = g.cuda().eval()
+    lr = torch.from_numpy(golden_inputs).cuda()
+    hr_np = W.synthetic_hr_batch(2, seed=1)
+    hr = torch.from_numpy(hr_np).cuda()
+    crit = RelativisticAverageLoss()
+    with torch.no_grad():
+        fake = g(lr)
+        real_logits, fake_logits = disc(hr), disc(fake)
+        d_loss, g_adv = crit.both_losses(real_logits, fake_logits)
+        pl = pixel_losses(fake, hr)
+    dsd = {k: v.cpu().numpy() for k, v in disc.state_dict().items()}
+    fake_ref = O.generator_forward(W.synthetic_state_dict_numpy(0), golden_inputs)
+    rl_ref, fl_ref = O.discriminator_forward(dsd, hr_np), O.discriminator_forward(dsd, fake_ref)
+    d_ref, g_ref = O.ragan_losses(rl_ref, fl_ref)
+    _, ssim_ref, _ = O.metrics(fake_ref, hr_np)
+    assert max_rel(fake_logits.cpu().numpy(), fl_ref) <= FP32_TOL
+    assert abs(d_loss.item() - d_ref) <= 1e-5 and abs(g_adv.item() - g_ref) <= 1e-5
+    assert abs(pl[3].item() - O.weighted_l1(fake_ref, hr_np)) <= 1e-5
+    assert abs(pl[1].item() - ssim_ref) <= 1e-4
