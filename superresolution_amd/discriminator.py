@@ -125,16 +125,20 @@ class Discriminator(nn.Module):
         p = self.backbone[0].weight
         if p.device != x.device:
             raise RuntimeError(f"Input type ({x.device}) and weight type ({p.device}) should be the same")
-        if x.dtype != torch.float32:
-            raise RuntimeError(f"unsupported input dtype {x.dtype}: the discriminator kernels are fp32")
+        # the reference runs D under torch.autocast(bfloat16) (train.py:150,166): bf16 inputs / bf16 autocast are
+        # accepted, the arithmetic stays fp32 (the stricter one) and only the returned logits are rounded
+        bf16_out = x.dtype == torch.bfloat16 or (
+            torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16)
+        if x.dtype not in (torch.float32, torch.bfloat16):
+            raise RuntimeError(f"unsupported input dtype {x.dtype}: fp32, or bf16 / bf16 autocast (computed in fp32)")
         _no_autograd("Discriminator.forward", x, *self.parameters())
-        xc = x.detach().contiguous()
+        xc = x.detach().float().contiguous()
         n, _, hgt, wid = xc.shape
         idx = xc.device.index
         oh, ow = self.out_size(hgt), self.out_size(wid)
         y = torch.empty((n, 1, oh, ow), dtype=torch.float32, device=xc.device)
         if n == 0:
-            return y
+            return y.to(torch.bfloat16) if bf16_out else y
         h = self._handle(idx)
         L = _lib.lib()
         need = ctypes.c_size_t()
@@ -160,7 +164,7 @@ class Discriminator(nn.Module):
             stream = torch.cuda.current_stream(idx).cuda_stream
             _lib.check(L.srdisc_forward(h, xc.data_ptr(), y.data_ptr(), ws.data_ptr(), ws.numel(), n, hgt, wid,
                                         arr, stream), "Discriminator")
-        return y
+        return y.to(torch.bfloat16) if bf16_out else y
 
     # ---- module protocol -------------------------------------------------------------------
     def _apply(self, fn, *a, **k):
@@ -199,12 +203,12 @@ class RelativisticAverageLoss(nn.Module):
             if not isinstance(t, torch.Tensor) or not t.is_cuda:
                 raise RuntimeError(f"RelativisticAverageLoss: `{nm}` must be a tensor on a ROCm device; there is "
                                    "no CPU fallback")
-            if t.dtype != torch.float32:
-                raise RuntimeError(f"RelativisticAverageLoss: `{nm}` is {t.dtype}; the kernel is fp32")
+            if t.dtype not in (torch.float32, torch.bfloat16):
+                raise RuntimeError(f"RelativisticAverageLoss: `{nm}` is {t.dtype}; fp32 or bf16 logits (computed in fp32)")
         if real.device != fake.device:
             raise RuntimeError(f"real is on {real.device}, fake on {fake.device}")
         _no_autograd("RelativisticAverageLoss", real, fake)
-        r, f = real.detach().contiguous(), fake.detach().contiguous()
+        r, f = real.detach().float().contiguous(), fake.detach().float().contiguous()   # BCEWithLogits autocasts to fp32
         out = torch.empty(2, dtype=torch.float32, device=r.device)
         if r.numel() == 0 or f.numel() == 0:
             return out.fill_(float("nan"))                  # mean of an empty tensor, as torch gives

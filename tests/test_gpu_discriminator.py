@@ -166,3 +166,19 @@ def test_gan_phase_forward_values_end_to_end(disc, golden_inputs):
     assert abs(d_loss.item() - d_ref) <= 1e-5 and abs(g_adv.item() - g_ref) <= 1e-5
     assert abs(pl[3].item() - O.weighted_l1(fake_ref, hr_np)) <= 1e-5
     assert abs(pl[1].item() - ssim_ref) <= 1e-4
+
+
+def test_bf16_autocast_surface(disc, gd, golden):
+    """train.py:150,166 call D and the criterion under torch.autocast(bfloat16): logits come back bf16 (fp32
+    arithmetic, rounded once), the loss fp32; both within bf16 rounding of the fp32 values."""
+    from superresolution_amd import RelativisticAverageLoss
+    sr = torch.from_numpy(golden["y_dense_sparse"]).cuda()
+    with torch.no_grad():
+        y32 = disc(sr)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            yb = disc(sr)
+            loss = RelativisticAverageLoss().generator_loss(yb, yb)
+        assert disc(sr.to(torch.bfloat16)).dtype == torch.bfloat16
+    assert yb.dtype == torch.bfloat16 and loss.dtype == torch.float32
+    assert torch.equal(yb, y32.to(torch.bfloat16))
+    assert np.isfinite(loss.item())
