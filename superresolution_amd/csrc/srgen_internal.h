@@ -132,7 +132,7 @@ hipError_t launch_ragan_loss(const float* real, const float* fake, size_t n_real
 // ---- train-mode BatchNorm over an NHWC (npix, 96) fp32 tensor, in place (srgen_kernels_misc.hip) ------------
 // t <- slope ? PReLU(bn(t)) : bn(t);  then, with res: t <- res + res_factor * t.  bn uses the batch mean and
 // the biased batch variance (eps 1e-5); batch_stats receives {mean[96], biased var[96]}.
-constexpr int kBnBlocks = 512;
+constexpr int kBnBlocks = 1024;
 size_t bn_scratch_bytes();
 hipError_t launch_bn_train(float* t, size_t npix, const float* gamma, const float* beta, const float* slope,
                            const float* res, float res_factor, void* scratch, float* batch_stats, hipStream_t s);

@@ -286,7 +286,18 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
         const size_t per = (npix + gridDim.x - 1) / gridDim.x;
         const size_t p0 = (size_t)blockIdx.x * per, p1 = p0 + per < npix ? p0 + per : npix;
         float sx[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
-        for (size_t p = p0 + row; p < p1; p += 10) {
+        size_t p = p0 + row;
+        for (; p + 30 < p1; p += 40) {                          // four loads in flight per thread
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(t + (p + 10 * u) * 96 + c4 * 4);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                sx[0] += v[u].x; sx[1] += v[u].y; sx[2] += v[u].z; sx[3] += v[u].w;
+                sq[0] += v[u].x * v[u].x; sq[1] += v[u].y * v[u].y; sq[2] += v[u].z * v[u].z; sq[3] += v[u].w * v[u].w;
+            }
+        }
+        for (; p < p1; p += 10) {
             const float4 v = *reinterpret_cast<const float4*>(t + p * 96 + c4 * 4);
             sx[0] += v.x; sx[1] += v.y; sx[2] += v.z; sx[3] += v.w;
             sq[0] += v.x * v.x; sq[1] += v.y * v.y; sq[2] += v.z * v.z; sq[3] += v.w * v.w;
@@ -313,9 +324,16 @@ __global__ __launch_bounds__(768) void bn_final_kernel(const double* partial, in
     __shared__ double tot[192];
     {   // 4 threads per column, fixed order
         const int col = threadIdx.x % 192, q = threadIdx.x / 192;
-        double a = 0.0;
-        for (int b = q; b < nb; b += 4) a += partial[(size_t)b * 192 + col];
-        part[q][col] = a;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;           // four loads in flight, fixed order
+        int b = q;
+        for (; b + 12 < nb; b += 16) {
+            a0 += partial[(size_t)b * 192 + col];
+            a1 += partial[(size_t)(b + 4) * 192 + col];
+            a2 += partial[(size_t)(b + 8) * 192 + col];
+            a3 += partial[(size_t)(b + 12) * 192 + col];
+        }
+        for (; b < nb; b += 4) a0 += partial[(size_t)b * 192 + col];
+        part[q][col] = (a0 + a1) + (a2 + a3);
     }
     __syncthreads();
     if (threadIdx.x < 192) tot[threadIdx.x] = (part[0][threadIdx.x] + part[1][threadIdx.x]) +
