@@ -51,6 +51,11 @@ def main():
     print(json.dumps({"metric": "discriminator_images_per_sec", "value": 2 * a.batch / (ms * 1e-3),
                       "unit": "images/s", "ms_per_step": ms, "batch": a.batch, "steps": a.steps,
                       "dtype": "f32", "gmac_per_image": macs / 1e9, "tflops": flops / (ms * 1e-3) / 1e12,
+                      "roofline": {"bound": "mfma", "achieved": flops / (ms * 1e-3) / 1e12, "peak": 157.3,
+                                   "unit": "TFLOP/s", "frac": flops / (ms * 1e-3) / 1e12 / 157.3,
+                                   "note": "whole step (stem, tail and loss launches included) against the nominal "
+                                           "fp32 MFMA peak; per-layer figures: tools/disc_layers.py on a rocprofv3 "
+                                           "kernel trace (profiles/r01_disc_layers.txt)"},
                       "loss_d": ld.item(), "loss_g": lg.item(),
                       "config": {"workload": "D(hr), D(sr) + RaGAN losses, batch 256 of 3x125x125 (train.py:152-154)"}}))
 
