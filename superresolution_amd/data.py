@@ -7,8 +7,8 @@ Mirrors, for the files the reference reads and writes around the hot path:
 * ``normalization_stats.pt`` (``dataset.py:104-113``; ``train.py:234`` reads ``['hr_p995']``);
 * checkpoints ``{'generator': state_dict, ...}`` (``train.py:119,124,213-225``; read at ``:268``).
 
-``JetImageDataset`` reproduces the reference's file split, worker sharding and per-file shuffle
-(same ``torch.Generator`` seed discipline => same sample order; fixture-tested).  What changes
+``JetImageDataset`` yields what the reference's dataset yields, in the same order (file split,
+round-robin worker sharding, per-chunk shuffle; pinned by ``tests/golden/dataset.npz``).  What changes
 is where the normalisation runs: with ``normalize=False`` the dataset yields RAW tensors and
 ``normalize_on_device`` applies ``clamp(x / hr_max, 0, 1)`` (``dataset.py:52-54``) with a HIP kernel
 after the H2D copy, bit-identically, instead of in the DataLoader workers.
@@ -18,7 +18,7 @@ from __future__ import annotations
 
 import glob
 import os
-from typing import Dict, Iterator, Tuple
+from typing import Dict, Iterator, List, Optional, Sequence, Tuple
 
 import torch
 from torch.utils.data import IterableDataset, get_worker_info
@@ -53,54 +53,63 @@ def load_generator_checkpoint(path: str, map_location="cpu"):
     return ck["generator"]
 
 
+_SPLITS = ("train", "val", "test")
+
+
+def split_chunk_files(files: Sequence[str], split: str, train_ratio: float, val_ratio: float) -> List[str]:
+    """The slice of the sorted chunk list a split owns: the first ``int(n * train_ratio)`` files train,
+    the next ``int(n * val_ratio)`` validate, the remainder tests (behaviour of ``dataset.py:14-24``)."""
+    if split not in _SPLITS:
+        raise ValueError(f"Invalid split: {split}")
+    cut_a = int(len(files) * train_ratio)
+    cut_b = cut_a + int(len(files) * val_ratio)
+    bounds = {"train": (0, cut_a), "val": (cut_a, cut_b), "test": (cut_b, len(files))}[split]
+    return list(files[bounds[0]:bounds[1]])
+
+
+def _loader_slot() -> Tuple[int, int]:
+    """(worker index, worker count) of the DataLoader process we are in; (0, 1) outside one."""
+    info = get_worker_info()
+    return (info.id, info.num_workers) if info is not None else (0, 1)
+
+
+def iter_chunk_samples(path: str, order_rng: torch.Generator, scale: Optional[float]):
+    """Samples of one chunk in a ``torch.randperm`` order drawn from ``order_rng``.  ``scale`` (the p99.5
+    statistic) applies ``clamp(x / scale, 0, 1)`` on the host, as the reference's workers do
+    (``dataset.py:52-54``); ``None`` yields raw values for :func:`normalize_on_device`.  The permutation is
+    drawn AFTER the load, so an unreadable chunk consumes no random numbers."""
+    lr, hr = load_chunk(path)
+    if scale:
+        lr, hr = (lr / scale).clamp_(0, 1), (hr / scale).clamp_(0, 1)
+    order = torch.randperm(lr.size(0), generator=order_rng)
+    yield from zip(lr[order].unbind(0), hr[order].unbind(0))
+
+
 class JetImageDataset(IterableDataset):
-    """Same constructor, split arithmetic, worker sharding and shuffle as ``dataset.py:7-61``."""
+    """Streams ``(lr, hr)`` pairs out of ``.pt`` chunk files with the reference's constructor and yield
+    order (``dataset.py:7-61``; ``tests/golden/dataset.npz`` was produced by iterating the reference's
+    class over the same files): files are dealt round-robin over DataLoader workers, each worker shuffles
+    inside a chunk with a generator seeded ``seed + worker index``, and a chunk that fails to load is
+    reported and skipped.  ``normalize=False`` keeps the host out of the normalisation."""
 
     def __init__(self, tensor_dir, split="train", train_ratio=0.8, val_ratio=0.1, hr_max=None, seed=42,
                  normalize=True):
         super().__init__()
-        all_files = list_chunk_files(tensor_dir)
-        if not all_files:
+        found = list_chunk_files(tensor_dir)
+        if not found:
             raise ValueError(f"No .pt files found in {tensor_dir}")
-        n = len(all_files)
-        n_train = int(n * train_ratio)
-        n_val = int(n * val_ratio)
-        if split == "train":
-            self.files = all_files[:n_train]
-        elif split == "val":
-            self.files = all_files[n_train:n_train + n_val]
-        elif split == "test":
-            self.files = all_files[n_train + n_val:]
-        else:
-            raise ValueError(f"Invalid split: {split}")
-        self.hr_max = hr_max
-        self.seed = seed
-        self.normalize = normalize
-
-    def _get_worker_files(self):
-        worker = get_worker_info()
-        if worker is None:
-            return self.files
-        return [f for i, f in enumerate(self.files) if i % worker.num_workers == worker.id]
+        self.files = split_chunk_files(found, split, train_ratio, val_ratio)
+        self.hr_max, self.seed, self.normalize = hr_max, seed, normalize
 
     def __iter__(self) -> Iterator[Tuple[torch.Tensor, torch.Tensor]]:
-        worker_info = get_worker_info()
-        worker_id = worker_info.id if worker_info else 0
-        rng = torch.Generator().manual_seed(self.seed + worker_id)
-        for path in self._get_worker_files():
+        slot, slots = _loader_slot()
+        order_rng = torch.Generator().manual_seed(self.seed + slot)
+        scale = self.hr_max if self.normalize else None
+        for path in self.files[slot::slots]:
             try:
-                lr, hr = load_chunk(path)
-            except Exception as e:                                         # dataset.py:48-50
-                print(f"Error loading {path}: {e}")
-                continue
-            if self.hr_max and self.normalize:                             # dataset.py:52-54
-                lr = torch.clamp(lr / self.hr_max, 0, 1)
-                hr = torch.clamp(hr / self.hr_max, 0, 1)
-            n = lr.size(0)
-            perm = torch.randperm(n, generator=rng)
-            lr, hr = lr[perm], hr[perm]
-            for i in range(n):
-                yield lr[i], hr[i]
+                yield from iter_chunk_samples(path, order_rng, scale)
+            except Exception as exc:                      # the reference keeps streaming (dataset.py:48-50)
+                print(f"Error loading {path}: {exc}")
 
 
 def normalize_on_device(x: torch.Tensor, hr_max: float, out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
