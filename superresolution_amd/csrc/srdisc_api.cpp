@@ -222,7 +222,8 @@ int srdisc_commit_weights(srdisc_handle* h, void* stream)
     }
 
     hipStream_t s = (hipStream_t)stream;
-    HIP_TRY(hipSetDevice(h->device));
+    DeviceScope on_device(h->device);
+    HIP_TRY(on_device.err);
     HIP_TRY(hipStreamSynchronize(s));                 // earlier forwards may still read the old blob
     if (h->blob_bytes < bytes.size()) {
         if (h->blob) HIP_TRY(hipFree(h->blob));

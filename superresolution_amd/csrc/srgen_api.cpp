@@ -58,8 +58,7 @@ inline uint16_t f32_to_bf16(float f)
 }
 
 struct ConvDev {           // offsets (bytes) into the device weight blob
-    size_t w_f32 = 0, w_wino = 0, w_wreg = 0, w_bf16 = 0, bias = 0, slope = 0;
-    bool has_wreg = false;
+    size_t w_f32 = 0, w_wino = 0, w_bf16 = 0, bias = 0, slope = 0;
     bool has_slope = false;
     int cout_blocks = 1;
 };
@@ -79,7 +78,6 @@ struct srgen_handle {
     CaDev ca[2];
     size_t zeros = 0;              // kWinoZeroBytes of zeros in the blob (Winograd halo padding rows)
     bool f32_wino = true;          // fp32 3x3 convs: Winograd F(2x2,3x3) kernel (default) or the direct one
-    bool f32_wreg = false;         // experimental: the register-only Winograd kernel on the trunk convs it covers
     // train-mode forward (srgen_forward_train): unfolded conv weights + BatchNorm affine parameters, built
     // lazily on the first train-mode call after a commit
     char* tblob = nullptr;         // device
@@ -232,29 +230,6 @@ std::vector<float> pack3x3_wino_f32(const Folded& f, int cb, const std::vector<i
     return p;
 }
 
-// Register-only Winograd kernel (srgen_conv3x3_f32_wreg.hip): float4 units [nu 4][chunk 6][xi 4][s 6][lane 64];
-// lane (m = lane & 15, kq = lane >> 4) holds U[xi][nu][co = 24*(m >> 2) + 4*s + (m & 3)][ci = 16*chunk + 4*kq + j].
-std::vector<float> pack3x3_wreg_f32(const Folded& f)
-{
-    static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
-    std::vector<float> p((size_t)16 * 96 * 96);
-    for (int nu = 0; nu < 4; ++nu)
-        for (int chunk = 0; chunk < 6; ++chunk)
-            for (int xi = 0; xi < 4; ++xi)
-                for (int s = 0; s < 6; ++s)
-                    for (int lane = 0; lane < 64; ++lane)
-                        for (int j = 0; j < 4; ++j) {
-                            const int m = lane & 15, kq = lane >> 4;
-                            const int co = 24 * (m >> 2) + 4 * s + (m & 3), ci = 16 * chunk + 4 * kq + j;
-                            const float* g = &f.w[((size_t)co * 96 + ci) * 9];
-                            double u = 0;
-                            for (int r = 0; r < 3; ++r)
-                                for (int c = 0; c < 3; ++c) u += G[xi][r] * (double)g[r * 3 + c] * G[nu][c];
-                            p[(((((size_t)nu * 6 + chunk) * 4 + xi) * 6 + s) * 64 + lane) * 4 + j] = (float)u;
-                        }
-    return p;
-}
-
 // bf16 image: 8-element units [cb][tap][ci/8][co 96] (8 consecutive ci per unit = one
 // 32x32x16 B fragment element group).
 std::vector<uint16_t> pack3x3_bf16(const Folded& f, int cb, const std::vector<int>& perm)
@@ -345,16 +320,12 @@ std::vector<int> identity_perm(int n)
 }
 
 ConvDev emit_conv3x3(Blob& blob, const Folded& f, int cb, const std::vector<int>& perm,
-                     const std::vector<float>* slope_src, bool slope_scalar, bool wreg = false)
+                     const std::vector<float>* slope_src, bool slope_scalar)
 {
     ConvDev d;
     d.cout_blocks = cb;
     d.w_f32 = blob.put_f32(pack3x3_f32(f, cb, perm));
     d.w_wino = blob.put_f32(pack3x3_wino_f32(f, cb, perm));
-    if (wreg && cb == 1) {
-        d.w_wreg = blob.put_f32(pack3x3_wreg_f32(f));
-        d.has_wreg = true;
-    }
     d.w_bf16 = blob.put_u16(pack3x3_bf16(f, cb, perm));
     std::vector<float> bias((size_t)cb * 96), slope((size_t)cb * 96, 1.f);
     for (int i = 0; i < cb * 96; ++i) {
@@ -428,10 +399,7 @@ int srgen_create(const srgen_config* cfg, srgen_handle** out)
     h->cfg = *cfg;
     h->device = dev;
     // development / test switch: SRGEN_F32_CONV3X3=direct selects the direct fp32 3x3 kernel
-    if (const char* e = getenv("SRGEN_F32_CONV3X3")) {
-        h->f32_wino = strcmp(e, "direct") != 0;
-        h->f32_wreg = strcmp(e, "wreg") == 0;         // experimental register-only Winograd kernel
-    }
+    if (const char* e = getenv("SRGEN_F32_CONV3X3")) h->f32_wino = strcmp(e, "direct") != 0;
     *out = h;
     return SRGEN_OK;
 }
@@ -494,9 +462,9 @@ int srgen_commit_weights(srgen_handle* h, void* stream)
     for (int i = 0; i < h->cfg.num_blocks; ++i) {                        // Generator.py:30-42
         const std::string p = "blocks." + std::to_string(seq_index(i)) + ".block";
         Folded f1 = fold(h, p + ".0", p + ".1", 1.0, 96, 96, 3);
-        h->conv1.push_back(emit_conv3x3(blob, f1, 1, id96, &h->tensors.at(p + ".2.weight"), false, h->f32_wreg));
+        h->conv1.push_back(emit_conv3x3(blob, f1, 1, id96, &h->tensors.at(p + ".2.weight"), false));
         Folded f2 = fold(h, p + ".3", p + ".4", 0.1, 96, 96, 3);
-        h->conv2.push_back(emit_conv3x3(blob, f2, 1, id96, nullptr, false, h->f32_wreg));
+        h->conv2.push_back(emit_conv3x3(blob, f2, 1, id96, nullptr, false));
         if (i == 7 || i == 15) {                                          // Generator.py:15-27
             const std::string q = "blocks." + std::to_string(seq_index(i) + 1) + ".fc";
             CaDev& c = h->ca[i == 7 ? 0 : 1];
@@ -508,7 +476,7 @@ int srgen_commit_weights(srgen_handle* h, void* stream)
     }
     {   // mid: conv + BN                                                  Generator.py:61-64
         Folded f = fold(h, "mid.0", "mid.1", 1.0, 96, 96, 3);
-        h->mid = emit_conv3x3(blob, f, 1, id96, nullptr, false, h->f32_wreg);
+        h->mid = emit_conv3x3(blob, f, 1, id96, nullptr, false);
     }
     {   // upsample conv 96 -> 384; PixelShuffle(2): out[c][2y+i][2x+j] = conv[4c+2i+j][y][x]
         // (Generator.py:7-8), so packed block b = 2i+j holds original channels 4c+b.
@@ -531,7 +499,8 @@ int srgen_commit_weights(srgen_handle* h, void* stream)
     }
 
     hipStream_t s = (hipStream_t)stream;
-    HIP_TRY(hipSetDevice(h->device));
+    DeviceScope on_device(h->device);
+    HIP_TRY(on_device.err);
     HIP_TRY(hipStreamSynchronize(s));                 // earlier forwards may still read the old blob
     if (h->blob_bytes < blob.bytes.size()) {
         if (h->blob) HIP_TRY(hipFree(h->blob));
@@ -589,7 +558,8 @@ static int prepare_train(srgen_handle* h, hipStream_t s)
     bn("mid.1");
     h->t_affine = blob.put_f32(affine);
     h->t_ones = blob.put_f32(std::vector<float>(96, 1.f));
-    HIP_TRY(hipSetDevice(h->device));
+    DeviceScope on_device(h->device);
+    HIP_TRY(on_device.err);
     HIP_TRY(hipStreamSynchronize(s));
     if (h->tblob_bytes < blob.bytes.size()) {
         if (h->tblob) HIP_TRY(hipFree(h->tblob));
@@ -656,11 +626,7 @@ static int run_forward(srgen_handle* h, const void* x, void* y, void* workspace,
         a.cout_blocks = d.cout_blocks; a.shuffle = shuffle;
         hipError_t e = tick(shuffle ? SRGEN_K_CONV3X3_UP : (H == kLR ? SRGEN_K_CONV3X3_TRUNK : SRGEN_K_CONV3X3_HR));
         if (e != hipSuccess) return e;
-        const bool wreg = wino && h->f32_wreg && d.has_wreg && H == kLR && !shuffle && !pool;
-        if (wreg) a.wpack = B + d.w_wreg;
-        e = bf ? launch_conv3x3_bf16(a, s)
-               : wreg ? launch_conv3x3_f32_wreg(a, s)
-                      : wino ? launch_conv3x3_f32_wino(a, s) : launch_conv3x3_f32(a, s);
+        e = bf ? launch_conv3x3_bf16(a, s) : wino ? launch_conv3x3_f32_wino(a, s) : launch_conv3x3_f32(a, s);
         if (e != hipSuccess) return e;
         return tock();
     };

@@ -10,6 +10,20 @@ namespace srgen {
 // records the message srgen_last_error() returns (thread-local) and returns `code`
 int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
 
+// Makes `device` current for a scope and puts the caller's device back afterwards (the weight uploads
+// allocate on the handle's device; the caller may be working on another one).
+struct DeviceScope {
+    int prev = -1;
+    hipError_t err;
+    explicit DeviceScope(int device)
+    {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != device) err = hipSetDevice(device);
+        else if (err == hipSuccess) prev = -1;          // already current: nothing to restore
+    }
+    ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
 constexpr int kC = 96;          // trunk width (base_ch)
 constexpr int kLR = 64;         // low-res side
 constexpr int kHR = 128;        // after PixelShuffle(2)
@@ -73,9 +87,6 @@ hipError_t launch_conv3x3_f32(const Conv3x3Args& a, hipStream_t s);
 // as float4 units [cb][nu 4][ci chunk 6][xi 4][ci/4 4][co 96]; needs Conv3x3Args::zeros; same
 // pool_partial tiling as the direct kernel
 hipError_t launch_conv3x3_f32_wino(const Conv3x3Args& a, hipStream_t s);
-// the same conv with every operand in registers (srgen_conv3x3_f32_wreg.hip): no LDS; wpack = U packed as
-// float4 units [nu 4][chunk 6][xi 4][s 6][lane 64]; 64x64 images, PReLU or residual epilogue
-hipError_t launch_conv3x3_f32_wreg(const Conv3x3Args& a, hipStream_t s);
 constexpr size_t kWinoZeroBytes = 64 * 96 * 4;        // one 64-pixel row of 96 channels
 hipError_t launch_chan_attn_f32(const ChanAttnArgs& a, hipStream_t s);
 hipError_t launch_head_f32(const HeadArgs& a, hipStream_t s);

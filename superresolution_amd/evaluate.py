@@ -51,24 +51,44 @@ def validate(generator: Callable[[torch.Tensor], torch.Tensor],
     """
     if metrics_fn is None:
         from .functional import batch_metrics as metrics_fn
+    # train.py:59,71: validate() switches the generator to eval for its own duration and back afterwards
+    # (it is called on a train-mode generator at train.py:104,193); without it a train-mode module would
+    # silently use batch statistics and overwrite its BatchNorm running statistics here.
+    module = generator if isinstance(generator, torch.nn.Module) else None
+    was_training = module.training if module is not None else False
+    if module is not None:
+        module.eval()
     acc = None
-    for lr, hr in batches:
-        if device is not None:
-            lr, hr = lr.to(device), hr.to(device)
-        sr = generator(lr.to(forward_dtype))
-        m = metrics_fn(sr.float(), hr.float()).to(torch.float64)
-        one = torch.ones(1, dtype=torch.float64, device=m.device)
-        v = torch.cat([m.reshape(3), one])
-        acc = v if acc is None else acc + v
+    try:
+        for lr, hr in batches:
+            if device is not None:
+                lr, hr = lr.to(device), hr.to(device)
+            sr = generator(lr.to(forward_dtype))
+            m = metrics_fn(sr.float(), hr.float()).to(torch.float64)
+            one = torch.ones(1, dtype=torch.float64, device=m.device)
+            v = torch.cat([m.reshape(3), one])
+            acc = v if acc is None else acc + v
+    finally:
+        if module is not None:
+            module.train(was_training)
     if acc is None:                                   # a rank may own no batch at all
-        dev = device if device is not None else torch.device("cpu")
-        acc = torch.zeros(4, dtype=torch.float64, device=dev)
+        acc = torch.zeros(4, dtype=torch.float64, device=_empty_shard_device(device, group))
     acc = reduce_metric_sums(acc, group)
     s = acc.cpu()
     n = float(s[3])
     if n == 0:
         raise ValueError("validate(): no batches on any rank")
     return float(s[0]) / n, float(s[1]) / n, float(s[2]) / n
+
+
+def _empty_shard_device(device: Optional[torch.device], group) -> torch.device:
+    """Where a rank with no batch builds its zero accumulator: RCCL ("nccl") reduces device tensors only, so
+    such a rank must not fall back to the CPU while its peers are already inside the collective."""
+    if device is not None:
+        return torch.device(device)
+    if dist.is_available() and dist.is_initialized() and "nccl" in str(dist.get_backend(group)):
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
 
 
 def batched(lr: torch.Tensor, hr: torch.Tensor, batch_size: int, which: Sequence[int]):

@@ -9,8 +9,9 @@ order, ``.to() / .eval() / .train() / .parameters()``, and ``generator(x)`` retu
 The sub-modules are stock ``torch.nn`` layers used purely as parameter containers; nothing
 here ever calls their ``forward``.  ``Generator.forward`` hands the input, an output tensor
 and a workspace to ``libsrgen.so`` (``include/srgen.h``) on the current HIP stream.  There
-is no eager-PyTorch or CPU fallback: a CPU tensor, train mode, or a missing extension
-raises.
+is no eager-PyTorch or CPU fallback: a CPU tensor or a missing extension raises.  The returned
+tensor never carries an autograd graph (the backward pass is not built): train mode under autograd,
+or an eval-mode input that requires grad, raise instead of silently yielding no gradient.
 """
 from __future__ import annotations
 
@@ -141,6 +142,11 @@ class Generator(nn.Module):
                 "Generator.forward in train mode under autograd (train.py:92,149,167): the backward pass is not "
                 "built. Train-mode forward VALUES (batch-statistics BatchNorm, running-statistics update) run "
                 "under torch.no_grad(); for inference call .eval(). There is no eager fallback.")
+        if not self.training and torch.is_grad_enabled() and isinstance(x, torch.Tensor) and x.requires_grad:
+            raise NotImplementedError(
+                "Generator.forward in eval mode with an input that requires grad: the backward pass is not built, "
+                "and the HIP forward returns a tensor with no autograd graph (it would silently give no gradient). "
+                "Detach the input or call under torch.no_grad().")
         if not isinstance(x, torch.Tensor) or x.dim() != 4:
             raise RuntimeError(f"Expected 4D (N, {self.in_ch}, 64, 64) input, got {tuple(getattr(x, 'shape', ()))}")
         if x.shape[1] != self.in_ch:
@@ -175,10 +181,17 @@ class Generator(nn.Module):
     def _run_train(self, x: torch.Tensor) -> torch.Tensor:
         """Train-mode forward values (``Generator.train()(x)`` without autograd): batch-statistics BatchNorm
         in the kernels, then the running-statistics update of ``nn.BatchNorm2d`` (momentum 0.1, unbiased
-        variance, ``num_batches_tracked += 1``) on this module's buffers.  fp32."""
+        variance, ``num_batches_tracked += 1``) on this module's buffers.
+
+        The kernels are fp32.  Under ``torch.autocast(bfloat16)`` -- the only way the reference calls the
+        train-mode forward (``train.py:91-92,148-149,166-167``) -- or with a bf16 input, the arithmetic still runs
+        in fp32 on ``x.float()`` and the result is rounded to bf16 once (the convention of ``Discriminator._run``):
+        stricter than autocast, whose convs round every layer; the statistics update stays fp32, as
+        ``nn.BatchNorm2d`` keeps it under autocast."""
         xc, code, dt = self._prepare(x)
+        out_dt = dt
         if code != _lib.SRGEN_F32:
-            raise RuntimeError("the train-mode forward is fp32 only (bf16 input or autocast is not built)")
+            xc, code, dt = xc.float(), _lib.SRGEN_F32, torch.float32
         n, idx = xc.shape[0], xc.device.index
         y = torch.empty((n, self.in_ch, self.OUT, self.OUT), dtype=dt, device=xc.device)
         if n == 0:
@@ -203,7 +216,7 @@ class Generator(nn.Module):
             torch._foreach_mul_(varis, 1 - mom)
             torch._foreach_add_(varis, [stats[k, 1] for k, _ in live], alpha=mom * m / max(m - 1, 1))
             torch._foreach_add_([bn.num_batches_tracked for _, bn in live], 1)
-        return y
+        return y if out_dt == dt else y.to(out_dt)
 
     def forward_taps(self, x: torch.Tensor):
         """(y, {tap name: NCHW fp32 tensor}) -- layer taps for parity tests (srgen_forward_taps)."""

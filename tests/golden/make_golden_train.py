@@ -12,6 +12,10 @@ Same conventions as make_golden.py (reference loaded by file path, only data is 
   mean1, var1     running_mean / running_var of every BatchNorm after the first forward  (33, 96)
   mean2, var2     ... after the second
   nbt             num_batches_tracked after the second forward
+
+`python tests/golden/make_golden_train.py bf16` writes generator_train_bf16.npz instead: the reference's train-mode
+forward of the seed-2 batch under torch.autocast(bfloat16) -- the way train.py:91-92,148-149,166-167 call it
+(CPU autocast here: no GPU in the build container) -- as float32 values of the bf16 output (y1_bf16_autocast).
 """
 import importlib.util
 import os
@@ -63,5 +67,18 @@ def main():
     print("wrote generator_train.npz:", {k: getattr(v, "shape", None) for k, v in out.items()})
 
 
+def main_bf16():
+    torch.set_num_threads(8)
+    G = load_ref("ref_generator", "Generator.py")
+    g = G.Generator()
+    g.load_state_dict(W.synthetic_state_dict(0), strict=True)
+    g.train()
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+        y = g(torch.from_numpy(train_batch(2)))
+    assert y.dtype == torch.bfloat16
+    np.savez_compressed(os.path.join(OUT, "generator_train_bf16.npz"), y1_bf16_autocast=y.float().numpy())
+    print("wrote generator_train_bf16.npz", tuple(y.shape))
+
+
 if __name__ == "__main__":
-    main()
+    main_bf16() if sys.argv[1:] == ["bf16"] else main()

@@ -82,3 +82,38 @@ def test_validate_two_ranks_equals_one_rank(tmp_path, nb):
 def test_validate_raises_without_batches():
     with pytest.raises(ValueError):
         E.validate(_fake_generator, [], metrics_fn=_oracle_metrics)
+
+
+class _ModeProbe(torch.nn.Module):
+    """Stand-in generator that records the mode it is called in (train.py:59,71 semantics of validate)."""
+
+    def __init__(self):
+        super().__init__()
+        self.seen = []
+
+    def forward(self, lr):
+        self.seen.append(self.training)
+        return _fake_generator(lr)
+
+
+def test_validate_runs_in_eval_mode_and_restores_training_flag():
+    lr, hr = _data(2, 2)
+    g = _ModeProbe().train()
+    E.validate(g, E.batched(lr, hr, 2, range(2)), metrics_fn=_oracle_metrics)
+    assert g.seen == [False, False] and g.training           # eval inside, train restored (train.py:71)
+    g = _ModeProbe().eval()
+    E.validate(g, E.batched(lr, hr, 2, range(2)), metrics_fn=_oracle_metrics)
+    assert g.seen == [False, False] and not g.training
+
+    def boom(sr, hr):
+        raise RuntimeError("metrics failed")
+    g = _ModeProbe().train()
+    with pytest.raises(RuntimeError, match="metrics failed"):
+        E.validate(g, E.batched(lr, hr, 2, range(1)), metrics_fn=boom)
+    assert g.training                                         # restored on the error path too
+
+
+def test_empty_shard_accumulator_device():
+    assert E._empty_shard_device(None, None) == torch.device("cpu")          # no process group: CPU
+    assert E._empty_shard_device(torch.device("cpu"), None) == torch.device("cpu")
+    assert E._empty_shard_device("cuda:0", None) == torch.device("cuda", 0)  # explicit device wins

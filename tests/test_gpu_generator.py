@@ -80,26 +80,6 @@ def test_fp32_direct_conv_kernel_matches_golden_and_winograd(gen, golden, golden
         assert max_rel(tw[nm].cpu().numpy(), td[nm].cpu().numpy()) <= 2e-5, nm
 
 
-def test_fp32_register_winograd_kernel_matches_golden_and_default(gen, golden, golden_inputs, monkeypatch):
-    """SRGEN_F32_CONV3X3=wreg routes the trunk convs (PReLU and residual epilogues) through the
-    register-only Winograd kernel (experimental): same bar as the default path, and
-    agreement with it far inside the bar on a batch that makes workgroups walk several items."""
-    from superresolution_amd import Generator, weights as W
-    monkeypatch.setenv("SRGEN_F32_CONV3X3", "wreg")
-    g = Generator()
-    g.load_state_dict(W.synthetic_state_dict(0))
-    g = g.cuda().eval()
-    x2 = torch.from_numpy(golden_inputs).cuda()
-    assert max_rel(g(x2).cpu().numpy(), golden["y_dense_sparse"]) <= FP32_TOL
-    for n in (1, 19, 40):
-        x = torch.from_numpy(W.synthetic_lr_batch(n, seed=11)).cuda()
-        yw, tw = gen.forward_taps(x)
-        yr, tr = g.forward_taps(x)
-        assert max_rel(yr.cpu().numpy(), yw.cpu().numpy()) <= 2e-5, n
-        for nm in ("block0", "block7", "ca8", "skip", "output1"):
-            assert max_rel(tr[nm].cpu().numpy(), tw[nm].cpu().numpy()) <= 2e-5, (n, nm)
-
-
 # ---- bf16 (BASELINE.json configs[2]) --------------------------------------------------------
 def _psnr(a, b):
     mse = float(np.mean((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2))
