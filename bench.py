@@ -1,34 +1,45 @@
 #!/usr/bin/env python3
 """bench.py -- generator images/s (64x64 -> 125x125) on N MI355X, one process per GPU.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype f32|bf16] [--batch B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype f32|bf16] [--workload cfg1|cfg2]
 
-A "step" is one eval forward of the drop-in ``Generator`` over one batch of synthetic LR images
-already resident in HBM.  At N=1 the workload is BASELINE.json configs[1]: fp32 eval inference
-(BN folded), batch 256 on one MI355X.  For N>1 (launched by torch.distributed.run) every rank
-runs the same per-GPU batch on its own images (weak scaling, images are independent: no
-data-path collective); the only collective is the metric all-reduce of evaluate(), outside the
-timed forward.  Rank 0 prints ONE JSON line.
+Launching.  `--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process touches no GPU, starts
+N children of itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, 127.0.0.1 rendezvous), waits for them and
+exits with their worst code.  Under torch.distributed.run (WORLD_SIZE already set) it is a rank.  A rank fails
+loudly when the ranks RCCL saw differ from --gpus; `n_gpus` on the line is dist.get_world_size().
 
-Extra objects on that line:
-  roofline      dominant kernel = the 33 trunk 3x3 convs, 75 % of the FLOPs: conv3x3_bf16_kernel<64,...>
-                or, for fp32, the Winograd kernel conv3x3_f32_wino_kernel<64,...> (SRGEN_F32_CONV3X3=direct
-                selects conv3x3_f32_kernel).  achieved = algorithmic FLOPs per launch (2*4096*96*864 per image x
-                batch) / average launch duration measured live with HIP events on the launch
-                stream (srgen_forward_profile); peak = 157.3 TFLOP/s fp32 matrix / 2500 TFLOP/s
-                bf16 dense (MI355X_MICROARCH.md); traffic = HBM bytes per launch from the committed
-                rocprofv3 PMC summary (profiles/traffic_<dtype>.json, tools/summarize_profiles.py:
-                FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate --pmc passes).
-  psnr          the "PSNR delta vs reference" half of BASELINE.json's metric: utils.psnr semantics
-                (srgen_metrics) against a synthetic target; for bf16 the delta to this library's fp32 path,
-                which the golden fixtures pin to the reference (bar 0.05 dB).
-  cpu_baseline  the reference's forward restated with stock torch CPU ops (oracle/torch_ref.py,
-                kind "port": same ATen conv kernels the reference dispatches) on the box's host
-                cores, batch 16, bounded to ~10-20 s.
+Workloads (BASELINE.json `configs`), both measured by every run and printed by rank 0 on ONE JSON line:
+  cfg1  (the headline, `value`)  a "step" is one eval forward of the drop-in Generator over one batch of 256
+        synthetic LR images already resident in HBM, fp32 (configs[1]); every rank runs its own 256 images
+        (weak scaling: images are independent, no data-path collective).  Exactly K steps are timed between
+        barrier + synchronize pairs (max over ranks) -> `value`; a second leg of >= 50 steps is timed step by
+        step with HIP events on the launch stream -> `median_ms_per_step` (BASELINE.md "GPU timing").
+  cfg2  (object `cfg2`)  configs[2] as specified: bf16, every rank owns 4 whole batches of 256 (8192 images at
+        8 GPUs), runs them through superresolution_amd.evaluate.validate -- generator forward, the PSNR/SSIM/L1
+        kernel per batch, sums kept on the device -- and ONE RCCL SUM all-reduce of {sum psnr, sum ssim, sum l1,
+        batches} ends it (train.py:57-72 semantics).  `--workload cfg2` makes this leg the headline instead.
+
+Further objects on the line:
+  roofline      dominant kernel = the 33 trunk 3x3 convs (75 % of the FLOPs).  `achieved` = FLOPs the matrix
+                pipe EXECUTES per launch / average launch duration measured live with HIP events on the launch
+                stream (srgen_forward_profile); `frac` = achieved / peak (157.3 TFLOP/s fp32 matrix, 2500 TFLOP/s
+                bf16 dense: MI355X_MICROARCH.md).  The fp32 kernel is Winograd F(2x2,3x3): it executes 16/36 of
+                the conv's algorithmic multiplies; the algorithmic rate (2*4096*96*864 FLOP per
+                image and launch) is reported beside it as `algorithmic_tflops` and may exceed the peak.
+                traffic = HBM bytes per launch from the committed rocprofv3 PMC summary (profiles/traffic_*.json).
+  bf16          the north-star dtype on the same line: batch-256 forward images/s, trunk conv ms per launch,
+                frac of the 2.5 PF peak, traffic, PSNR delta.
+  psnr          the "PSNR delta vs reference" half of the metric: this library's output on the two golden inputs
+                against the REFERENCE's output for them (tests/golden/generator_fp32.npz, written by running the
+                real reference), both scored with utils.psnr semantics against the same synthetic target.
+  cpu_baseline  the reference's forward restated with stock torch CPU ops (oracle/torch_ref.py, kind "port") on
+                the box's host cores, batch 16, bounded to ~10-20 s.  Runs BEFORE the GPU legs.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -38,10 +49,12 @@ sys.path.insert(0, ROOT)
 FLOP_PER_IMAGE = 2 * 14_407_045_632
 TRUNK_CONV_FLOP_PER_IMAGE = 2 * 4096 * 96 * 864  # one 96->96 3x3 conv at 64x64
 PEAK = {"f32": 157.3, "bf16": 2500.0}          # dense TFLOP/s, MI355X_MICROARCH.md
+WINO_EXECUTED = 16.0 / 36.0                    # F(2x2,3x3): multiplies executed / algorithmic
+BATCH = 256                                    # config.py:8, the reference batch
+CFG2_BATCHES_PER_GPU = 4                       # 8192 images / 256 / 8 GPUs
 
 
 def cpu_baseline(batch=16, iters=64, threads=None):
-    import numpy as np
     import torch
     from oracle import torch_ref
     from superresolution_amd import weights as W
@@ -59,128 +72,249 @@ def cpu_baseline(batch=16, iters=64, threads=None):
                       f"(stock torch CPU conv path), {dt:.1f} s"}
 
 
+def spawn_ranks(n, argv):
+    """One child process per GPU, started before this process has made any GPU call."""
+    import torch
+    have = torch.cuda.device_count()                  # counts devices without initialising the GPU
+    if have < n:
+        raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible; refusing to report an {n}-GPU number")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    deadline = time.time() + 1500
+    codes = [None] * n
+    while any(c is None for c in codes):
+        for i, p in enumerate(procs):
+            if codes[i] is None:
+                codes[i] = p.poll()
+        failed = [c for c in codes if c not in (None, 0)]
+        if failed or time.time() > deadline:
+            for i, p in enumerate(procs):             # a rank died or hung: end exactly the children we started
+                if codes[i] is None:
+                    p.kill()
+                    codes[i] = p.wait()
+            break
+        time.sleep(0.2)
+    bad = [c for c in codes if c != 0]
+    raise SystemExit(bad[0] if bad else 0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32")
-    ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default=None, help="dtype of the cfg1 leg (default f32)")
+    ap.add_argument("--workload", choices=["cfg1", "cfg2"], default="cfg1", help="which leg is the headline `value`")
+    ap.add_argument("--batch", type=int, default=BATCH, help="images per GPU per step (cfg1)")
+    ap.add_argument("--cfg2-reps", type=int, default=5)
+    ap.add_argument("--median-steps", type=int, default=50, help="HIP-event-timed steps of the median leg (>= 50)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-run", action="store_true", help="ranks report their rendezvous environment and exit "
+                    "(launcher rehearsal on a box without GPUs)")
     args = ap.parse_args()
-
-    import torch
-    import torch.distributed as dist
-    from superresolution_amd import Generator, weights as W
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus, sys.argv[1:])
+        return
+    dtype = args.dtype or "f32"
+    if args.dry_run:
+        print(json.dumps({k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}),
+              flush=True)
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a number for the wrong rank count")
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()                          # host-only leg first: the GPU legs then run back to back
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from superresolution_amd import Generator, evaluate as E, weights as W
+    from superresolution_amd.functional import batch_metrics
+
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    use_dist = world > 1 or bool(os.environ.get("SRGEN_BENCH_FORCE_DIST"))   # the latter: 1-rank rehearsal
+    use_dist = world > 1 or bool(os.environ.get("SRGEN_BENCH_FORCE_DIST"))   # the latter: 1-rank RCCL rehearsal
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"RCCL sees {dist.get_world_size()} rank(s), --gpus {args.gpus}")
+    n_ranks = dist.get_world_size() if use_dist else 1
 
     g = Generator()
     g.load_state_dict(W.synthetic_state_dict(0))
     g = g.to(dev).eval()
     # per-rank synthetic LR batch (different images per rank), resident in HBM before timing
     gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
-    x = torch.rand((args.batch, 3, 64, 64), generator=gen).to(dev)
-    if args.dtype == "bf16":
-        x = x.to(torch.bfloat16)
+    x32 = torch.rand((args.batch, 3, 64, 64), generator=gen).to(dev)
+    xs = {"f32": x32, "bf16": x32.to(torch.bfloat16)}
 
     def barrier():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        y = g(x)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        y = g(x)
-    barrier()
-    dt = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    def max_over_ranks(v):
+        if not use_dist:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    assert torch.isfinite(y.float()).all()
+        return float(t.item())
 
-    # ---- roofline leg: live HIP-event timing of the dominant kernel ----------------------
-    roof = None
-    kernels = {}
-    if rank == 0:
+    def timed_forward(dt_name, steps, warmup):
+        """The contract's region: W untimed steps, then exactly K steps between barrier + synchronize pairs."""
+        x = xs[dt_name]
+        for _ in range(warmup):
+            y = g(x)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            y = g(x)
+        barrier()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        assert torch.isfinite(y.float()).all()
+        return dt
+
+    def median_forward(dt_name, steps, min_seconds=0.0, cap=400):
+        """Per-step HIP events on the stream the forward launches on (torch's current stream); median."""
+        x = xs[dt_name]
+        evs = [torch.cuda.Event(enable_timing=True)]
+        evs[0].record()
+        t0 = time.perf_counter()
+        done = 0
+        while done < steps or (time.perf_counter() - t0 < min_seconds and done < cap):
+            g(x)
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            evs.append(e)
+            done += 1
+            if done % 16 == 0:
+                e.synchronize()                       # keep the launch queue short: honest per-step intervals
+        evs[-1].synchronize()
+        ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(done))
+        return {"steps": done, "median_ms_per_step": round(ms[done // 2], 4), "min_ms_per_step": round(ms[0], 4),
+                "p90_ms_per_step": round(ms[int(done * 0.9)], 4)}
+
+    def kernel_profile(dt_name, reps=3):
         acc = {}
-        reps = 3
         for _ in range(reps):
-            for k, (ms, cnt) in g.profile_forward(x).items():
+            for k, (ms, cnt) in g.profile_forward(xs[dt_name]).items():
                 a = acc.setdefault(k, [0.0, 0])
                 a[0] += ms
                 a[1] += cnt
-        kernels = {k: {"ms_per_launch": round(v[0] / max(v[1], 1), 4), "launches_per_forward": v[1] // reps}
-                   for k, v in acc.items()}
-        ms_launch = acc["conv3x3_trunk"][0] / acc["conv3x3_trunk"][1]
-        achieved = TRUNK_CONV_FLOP_PER_IMAGE * args.batch / (ms_launch * 1e-3) / 1e12
+        return {k: {"ms_per_launch": round(v[0] / max(v[1], 1), 4), "launches_per_forward": v[1] // reps}
+                for k, v in acc.items()}
+
+    def roofline(dt_name, kernels):
+        ms_launch = kernels["conv3x3_trunk"]["ms_per_launch"]
+        algorithmic = TRUNK_CONV_FLOP_PER_IMAGE * args.batch / (ms_launch * 1e-3) / 1e12
+        wino = dt_name == "f32" and os.environ.get("SRGEN_F32_CONV3X3") != "direct"
+        executed = algorithmic * (WINO_EXECUTED if wino else 1.0)
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", f"traffic_{args.dtype}.json")
+        tpath = os.path.join(ROOT, "profiles", f"traffic_{dt_name}.json")
         if os.path.exists(tpath):
             try:
                 traffic = json.load(open(tpath)).get("conv3x3_trunk_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        wino = args.dtype == "f32" and os.environ.get("SRGEN_F32_CONV3X3") != "direct"
-        kname = "conv3x3_f32_wino_kernel<64,false,*,*,*>" if wino else f"conv3x3_{args.dtype}_kernel<64,false,*,*>"
-        roof = {"bound": "mfma", "kernel": f"{kname} (33 trunk launches)",
-                "achieved": round(achieved, 2), "peak": PEAK[args.dtype], "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK[args.dtype], 4), "traffic": traffic,
-                "ms_per_launch": round(ms_launch, 4),
-                "flop_per_launch": TRUNK_CONV_FLOP_PER_IMAGE * args.batch}
-        if wino:
-            # Winograd F(2x2,3x3) multiplies 16 instead of 36 times per (ci, co, 2x2 outputs): the
-            # matrix pipe executes 4/9 of the algorithmic FLOPs, so `frac` (algorithmic / peak) can
-            # exceed 1; what the MFMA units are actually kept busy with is mfma_executed.
-            roof["mfma_executed"] = round(achieved * 16 / 36, 2)
-            roof["mfma_executed_frac"] = round(achieved * 16 / 36 / PEAK[args.dtype], 4)
-            roof["note"] = ("Winograd F(2x2,3x3): achieved/frac count the conv's algorithmic FLOPs (SURVEY 8d); "
-                            "the kernel executes 4/9 of them on the matrix pipe (mfma_executed)")
+        kname = "conv3x3_f32_wino_kernel<64,false,*,*,*>" if wino else f"conv3x3_{dt_name}_kernel<64,false,*,*>"
+        return {"bound": "mfma", "kernel": f"{kname} (33 trunk launches)", "achieved": round(executed, 2),
+                "peak": PEAK[dt_name], "unit": "TFLOP/s", "frac": round(executed / PEAK[dt_name], 4),
+                "traffic": traffic, "ms_per_launch": ms_launch,
+                "flop_per_launch_executed": int(TRUNK_CONV_FLOP_PER_IMAGE * args.batch * (WINO_EXECUTED if wino else 1.0)),
+                "flop_per_launch_algorithmic": TRUNK_CONV_FLOP_PER_IMAGE * args.batch,
+                "algorithmic_tflops": round(algorithmic, 2),
+                "counts": ("FLOPs the matrix pipe executes: Winograd F(2x2,3x3) runs 16/36 of the direct conv's "
+                           "multiplies" if wino else "algorithmic = executed (direct implicit GEMM)")}
 
-    # ---- PSNR delta (the second half of BASELINE.json's metric), outside the timed region ---------
-    # psnr(y, hr) per utils.psnr (srgen_metrics) against a synthetic target; for bf16 the delta to the fp32
-    # path of this library on the same weights and inputs (the fp32 path itself is pinned to the
-    # reference's output by the golden fixtures: tests/test_gpu_generator.py, <= 1e-4, measured 2e-6).
-    psnr = None
-    if rank == 0:
-        from superresolution_amd.functional import batch_metrics
-        hr = torch.rand((args.batch, 3, 125, 125), generator=torch.Generator(device="cpu").manual_seed(1)).to(dev)
-        y32 = g(x.float()).clamp(0, 1)
-        p32 = float(batch_metrics(y32, hr)[0])
-        psnr = {"psnr_fp32_path_db": round(p32, 4)}
-        if args.dtype == "bf16":
-            yb = y.float().clamp(0, 1)
-            pb = float(batch_metrics(yb, hr)[0])
-            psnr.update({"psnr_bf16_path_db": round(pb, 4), "psnr_delta_db": round(pb - p32, 5),
-                         "psnr_bf16_vs_fp32_output_db": round(float(batch_metrics(yb, y32)[0]), 2),
-                         "bar": "|delta| <= 0.05 dB (BASELINE.json north_star)"})
+    def psnr_vs_reference():
+        """PSNR delta vs the reference: this library's output on the two golden inputs against the reference's
+        own output for them (fixture written by the real reference), same target, utils.psnr semantics."""
+        gold = np.load(os.path.join(ROOT, "tests", "golden", "generator_fp32.npz"))
+        ref = torch.from_numpy(gold["y_dense_sparse"]).to(dev)
+        xin = torch.from_numpy(np.concatenate([W.synthetic_lr_batch(1, 0, "dense"),
+                                               W.synthetic_lr_batch(1, 0, "sparse")], 0)).to(dev)
+        hr = torch.from_numpy(W.synthetic_hr_batch(2, seed=1)).to(dev)
+        p_ref = float(batch_metrics(ref, hr)[0])
+        out = {"target": "synthetic hr seed 1, golden inputs (dense, sparse), weights seed 0",
+               "psnr_reference_output_db": round(p_ref, 5), "bar_bf16": "|delta| <= 0.05 dB (BASELINE.json north_star)"}
+        for name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+            y = g(xin.to(dt)).float()
+            p = float(batch_metrics(y, hr)[0])
+            out[f"psnr_{name}_db"] = round(p, 5)
+            out[f"psnr_delta_{name}_db"] = round(p - p_ref, 6)
+            out[f"psnr_{name}_vs_reference_output_db"] = round(float(batch_metrics(y, ref)[0]), 2)
+            out[f"max_rel_err_{name}"] = float((y - ref).abs().max() / ref.abs().max())
+        return out
 
-    # ---- HBM-bound kernels of the path: achieved GB/s against the 8 TB/s HBM3E peak ------------
-    hbm = {}
+    def cfg2_leg(reps):
+        """configs[2]: bf16, this rank's 4 batches of 256 through validate() + the RCCL metric all-reduce."""
+        nb = CFG2_BATCHES_PER_GPU
+        gl = torch.Generator(device="cpu").manual_seed(4321 + rank)
+        lr = torch.rand((nb * BATCH, 3, 64, 64), generator=gl).to(dev)
+        gh = torch.Generator(device=dev).manual_seed(1 + rank)                  # hr target generated on the device
+        hr = torch.rand((nb * BATCH, 3, 125, 125), generator=gh, device=dev)
+        mine = E.shard_batches(nb * n_ranks, rank, n_ranks)
+        assert len(mine) == nb
+
+        def run():
+            return E.validate(g, E.batched(lr, hr, BATCH, range(nb)), device=dev, forward_dtype=torch.bfloat16)
+        m = run()                                                               # warm-up (workspace, RCCL channel)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            m = run()
+        barrier()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        imgs = nb * BATCH * n_ranks * reps
+        return {"workload": f"BASELINE.json configs[2]: bf16, {nb * BATCH * n_ranks} images = {nb} batches of {BATCH} per "
+                            f"GPU x {n_ranks} GPU(s), evaluate.validate (forward + PSNR/SSIM/L1 kernel per batch) + one "
+                            "RCCL SUM all-reduce of 4 scalars" + ("" if use_dist else " (single process: no process group)"),
+                "images_per_s": round(imgs / dt, 2), "ms_per_validate": round(dt / reps * 1e3, 3), "reps": reps,
+                "n_gpus": n_ranks, "collective": "nccl all_reduce(SUM, 4 x f64)" if use_dist else None,
+                "metrics_mean_over_batches": {"psnr": round(m[0], 5), "ssim": round(m[1], 6), "l1": round(m[2], 6)},
+                "_dt": dt, "_imgs": imgs}
+
+    # ---- legs ---------------------------------------------------------------------------------------------
+    dt_main = timed_forward(dtype, args.steps, args.warmup)
+    med = median_forward(dtype, max(50, args.median_steps), min_seconds=4.0 if world == 1 else 0.0)
+    other = "bf16" if dtype == "f32" else "f32"
+    dt_other = timed_forward(other, max(20, args.steps // 2), 3)
+    steps_other = max(20, args.steps // 2)
+    med_other = median_forward(other, 50)
+    c2 = cfg2_leg(args.cfg2_reps)
+
+    out = None
     if rank == 0:
-        elt = 2 if args.dtype == "bf16" else 4
-        ca_bytes = 2 * args.batch * 64 * 64 * 96 * elt          # one read + one write (pool fused upstream)
-        ca_ms = kernels["chan_attn"]["ms_per_launch"]
-        hbm["chan_attn"] = {"algorithmic_bytes": ca_bytes, "ms_per_launch": ca_ms,
-                            "GBps": round(ca_bytes / (ca_ms * 1e-3) / 1e9, 1),
-                            "frac_of_8TBps": round(ca_bytes / (ca_ms * 1e-3) / 8e12, 3)}
+        kern = {d: kernel_profile(d) for d in ("f32", "bf16")}
+        roofs = {d: roofline(d, kern[d]) for d in ("f32", "bf16")}
+        psnr = psnr_vs_reference()
+        hbm = {}
+        for d, elt in (("f32", 4), ("bf16", 2)):
+            ca_bytes = 2 * args.batch * 64 * 64 * 96 * elt          # one read + one write (pool fused upstream)
+            ca_ms = kern[d]["chan_attn"]["ms_per_launch"]
+            hbm[f"chan_attn_{d}"] = {"algorithmic_bytes": ca_bytes, "ms_per_launch": ca_ms,
+                                     "GBps": round(ca_bytes / (ca_ms * 1e-3) / 1e9, 1),
+                                     "frac_of_8TBps": round(ca_bytes / (ca_ms * 1e-3) / 8e12, 3)}
         from superresolution_amd import bilinear_resize
         z = torch.rand((args.batch, 3, 128, 128), device=dev)
         for _ in range(3):
@@ -198,29 +332,51 @@ def main():
                                              "frac_of_8TBps": round(rs_bytes / (rs_ms * 1e-3) / 8e12, 3),
                                              "note": "optional op, not on the forward path (the reference crops)"}
 
-    if rank == 0:
-        imgs = args.batch * world * args.steps
-        value = imgs / dt
+        def fwd_obj(d, dt, steps, md):
+            v = args.batch * n_ranks * steps / dt
+            wino = d == "f32" and os.environ.get("SRGEN_F32_CONV3X3") != "direct"
+            return {"images_per_s": round(v, 2), "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps, **md,
+                    "end_to_end_algorithmic_tflops": round(v * FLOP_PER_IMAGE / 1e12, 2),
+                    "end_to_end_frac_of_peak": round(v / n_ranks * FLOP_PER_IMAGE / 1e12 / PEAK[d]
+                                                     * (WINO_EXECUTED_E2E if wino else 1.0), 4),
+                    "trunk_ms_per_launch": kern[d]["conv3x3_trunk"]["ms_per_launch"],
+                    "trunk_frac_of_peak": roofs[d]["frac"], "traffic": roofs[d]["traffic"],
+                    "psnr_delta_vs_reference_db": psnr[f"psnr_delta_{d}_db"]}
+
+        main_obj = fwd_obj(dtype, dt_main, args.steps, med)
+        other_obj = fwd_obj(other, dt_other, steps_other, med_other)
+        cfg1_name = (f"BASELINE.json configs[1]: Generator eval inference (BN folded), batch {args.batch} of 3x64x64 per "
+                     f"GPU -> 3x125x125, {dtype}" + ("" if dtype == "f32" else " (configs[1]'s shape at configs[2]'s dtype)"))
+        headline_cfg2 = args.workload == "cfg2"
+        value = c2["images_per_s"] if headline_cfg2 else main_obj["images_per_s"]
+        ms_step = c2["ms_per_validate"] if headline_cfg2 else main_obj["ms_per_step"]
         out = {
-            "metric": "generator images/s (64x64->125x125)", "value": round(value, 2), "unit": "images/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"BASELINE.json configs[{1 if args.dtype == 'f32' else 2}]"
-                                   f"{'' if args.dtype == 'f32' else ' (its bf16 path, one 256-image batch per GPU)'}: "
-                                   "Generator eval inference (BN folded), "
-                                   f"batch {args.batch} of 3x64x64 per GPU -> 3x125x125, {args.dtype}",
-                       "batch_per_gpu": args.batch, "global_batch": args.batch * world,
-                       "parallelism": f"batch-sharded x{world}, weights replicated"},
-            "end_to_end_tflops": round(value * FLOP_PER_IMAGE / 1e12, 2),
-            "end_to_end_frac_of_peak": round(value / world * FLOP_PER_IMAGE / 1e12 / PEAK[args.dtype], 4),
-            "roofline": roof, "kernels": kernels, "hbm_kernels": hbm, "psnr": psnr,
+            "metric": "generator images/s (64x64->125x125)", "value": value, "unit": "images/s",
+            "n_gpus": n_ranks, "steps": c2["reps"] if headline_cfg2 else args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_step, "median_ms_per_step": None if headline_cfg2 else med["median_ms_per_step"],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if headline_cfg2 else dtype, "data": "synthetic",
+            "config": {"workload": c2["workload"] if headline_cfg2 else cfg1_name,
+                       "batch_per_gpu": BATCH * CFG2_BATCHES_PER_GPU if headline_cfg2 else args.batch,
+                       "global_batch": (BATCH * CFG2_BATCHES_PER_GPU if headline_cfg2 else args.batch) * n_ranks,
+                       "parallelism": f"batch-sharded x{n_ranks}, weights replicated, one process per GPU"},
+            "roofline": roofs["bf16" if headline_cfg2 else dtype],
+            dtype: main_obj, other: other_obj,
+            "cfg2": {k: v for k, v in c2.items() if not k.startswith("_")},
+            "kernels": kern[dtype], f"kernels_{other}": kern[other], "roofline_" + other: roofs[other],
+            "hbm_kernels": hbm, "psnr": psnr,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
     if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+# end-to-end executed share for the fp32 path: the 36 3x3 convs (96.7 % of the FLOPs) run Winograd, the 9x9 stem and
+# head (3.3 %) run direct -> executed / algorithmic over the whole forward
+WINO_EXECUTED_E2E = (0.9668 * WINO_EXECUTED + 0.0332)
 
 
 if __name__ == "__main__":

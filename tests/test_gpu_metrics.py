@@ -85,3 +85,54 @@ def test_validate_on_hip_path_matches_oracle(golden_inputs):
     per = [O.metrics(O.generator_forward(sd, golden_inputs[i:i + 1]), hr[i:i + 1].numpy()) for i in range(2)]
     want = np.mean(np.array(per), axis=0)
     assert abs(got[0] - want[0]) <= 1e-3 and abs(got[1] - want[1]) <= 1e-5 and abs(got[2] - want[2]) <= 1e-6
+
+
+def _big_eval_set(nb, bs):
+    from superresolution_amd import weights as W
+    lr = torch.from_numpy(W.synthetic_lr_batch(nb * bs, seed=31, kind="dense"))
+    hr = torch.from_numpy(W.synthetic_hr_batch(nb * bs, seed=32))
+    return lr, hr
+
+
+def test_validate_bf16_four_batches_of_256():
+    """BASELINE.json configs[2], one rank's share: bf16, 4 batches of 256 through evaluate.validate
+    (train.py:57-72 semantics) == the hand mean of per-batch batch_metrics, and its PSNR within 0.05 dB of the
+    fp32 path on the same data (north_star's bf16 bar)."""
+    from superresolution_amd import Generator, batch_metrics, evaluate as E, weights as W
+    g = Generator()
+    g.load_state_dict(W.synthetic_state_dict(0))
+    g = g.cuda().eval()
+    nb, bs = 4, 256
+    lr, hr = _big_eval_set(nb, bs)
+    dev = torch.device("cuda")
+    got = E.validate(g, E.batched(lr, hr, bs, range(nb)), device=dev, forward_dtype=torch.bfloat16)
+    per = []
+    for b in range(nb):
+        sl = slice(b * bs, (b + 1) * bs)
+        sr = g(lr[sl].cuda().to(torch.bfloat16))
+        assert sr.dtype == torch.bfloat16
+        per.append(batch_metrics(sr.float(), hr[sl].cuda()).double().cpu())
+    hand = torch.stack(per).mean(0).numpy()
+    assert np.allclose(np.array(got), hand, rtol=0, atol=1e-9)
+    f32 = E.validate(g, E.batched(lr, hr, bs, range(nb)), device=dev)
+    print("validate 4x256: bf16", got, "fp32", f32)
+    assert abs(got[0] - f32[0]) <= 0.05
+    assert abs(got[1] - f32[1]) <= 1e-3 and abs(got[2] - f32[2]) <= 1e-3
+
+
+def test_validate_on_train_mode_generator_uses_eval_and_leaves_buffers():
+    """train.py:59,71,104: validate() is called on a train-mode generator; it must evaluate with running
+    statistics, leave every BatchNorm buffer untouched and hand the module back in train mode."""
+    from superresolution_amd import Generator, evaluate as E, weights as W
+    g = Generator()
+    g.load_state_dict(W.synthetic_state_dict(0))
+    g = g.cuda()
+    lr, hr = _big_eval_set(2, 3)
+    want = E.validate(g.eval(), E.batched(lr, hr, 3, range(2)), device=torch.device("cuda"))
+    before = {k: v.clone() for k, v in g.state_dict().items()}
+    g.train()
+    got = E.validate(g, E.batched(lr, hr, 3, range(2)), device=torch.device("cuda"))
+    assert g.training
+    assert got == want
+    after = g.state_dict()
+    assert all(torch.equal(before[k], after[k]) for k in before)

@@ -96,3 +96,29 @@ def test_synthetic_weights_are_deterministic_and_nontrivial():
     assert got == pinned
     x = W.synthetic_lr_batch(2, 0, "sparse")
     assert x.shape == (2, 3, 64, 64) and 0.95 < (x == 0).mean() < 0.99 and x.max() <= 1.0
+
+
+def test_bench_launcher_starts_one_rank_per_gpu_without_touching_the_gpu(monkeypatch, capfd):
+    """bench.py --gpus N (N > 1, no WORLD_SIZE): the parent starts N children with the torchrun environment
+    (127.0.0.1 rendezvous) and exits with their worst code; with fewer visible GPUs than N it refuses."""
+    import importlib
+    import json
+    import torch
+    bench = importlib.import_module("bench")
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 3)
+    with pytest.raises(SystemExit) as e:
+        bench.spawn_ranks(3, ["--gpus", "3", "--dry-run"])
+    assert e.value.code == 0
+    lines = [json.loads(l) for l in capfd.readouterr().out.splitlines() if l.startswith("{")]
+    assert sorted(int(l["RANK"]) for l in lines) == [0, 1, 2]
+    assert all(l["WORLD_SIZE"] == "3" and l["MASTER_ADDR"] == "127.0.0.1" and l["LOCAL_RANK"] == l["RANK"] for l in lines)
+    assert len({l["MASTER_PORT"] for l in lines}) == 1
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    with pytest.raises(SystemExit, match="only 1 GPU"):
+        bench.spawn_ranks(2, ["--gpus", "2", "--dry-run"])
+    # a failing rank fails the launch
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 2)
+    with pytest.raises(SystemExit) as e:
+        bench.spawn_ranks(2, ["--gpus", "2", "--no-such-flag"])
+    assert e.value.code not in (0, None)
