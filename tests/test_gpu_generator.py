@@ -284,11 +284,10 @@ def test_pixel_shuffle_store_is_bit_exact_on_hip(dtype, direct, monkeypatch):
     g.load_state_dict(_shuffle_kat_state_dict())
     g = g.cuda().eval()
     n = 3
-    i = torch.arange(n * 3 * 64 * 64, dtype=torch.int64).view(n, 3, 64, 64)
     hh, ww = torch.arange(64).view(1, 1, 64, 1), torch.arange(64).view(1, 1, 1, 64)
     x = (((hh * 7 + ww * 3 + torch.arange(3).view(1, 3, 1, 1) * 5 + torch.arange(n).view(n, 1, 1, 1) * 11) % 13) - 6)
     x = x.to(torch.float32)
-    assert i.shape == x.shape
+    assert x.shape == (n, 3, 64, 64)
     c = torch.arange(96)
     m = (1 + (c // 3) % 4).view(1, 96, 1, 1).float() * x[:, c % 3]                       # x1 = skip, integers
     oc = torch.arange(384)
@@ -301,7 +300,8 @@ def test_pixel_shuffle_store_is_bit_exact_on_hip(dtype, direct, monkeypatch):
     got = taps["upsample"].cpu()
     assert got.shape == (n, 96, 128, 128)
     assert torch.equal(got, want)
-    assert want.abs().max() <= 96 and want.unique().numel() > 60
+    top, distinct = float(want.abs().max()), int(want.unique().numel())
+    assert top <= 96 and distinct > 40, (top, distinct)
 
 
 def test_pixel_shuffle_fixture_agrees_with_the_permutation_used_above():
