@@ -233,12 +233,14 @@ hipError_t launch_chan_attn_bf16(const ChanAttnArgs& a, hipStream_t s)
 // Head, bf16: Conv2d(96, 3, 9, padding=4) + crop -- Generator.py:71,80.  Same (kx -> N)
 // reformulation as the fp32 head: T[y][x'][kx*3+co] = sum_{ky,ci} in[y+ky-4][x'][ci] w[...],
 // out[y][x][co] = bias + sum_kx T[y][x+kx-4][kx*3+co].
-// LDS: 12 rows x 160 cols x 16 ci per chunk as two planes [k half][pixel][16 B] (61,440 B),
-// re-used for T (4 x 160 x 29 floats) in the epilogue.
+// x' runs over the 128 image columns only (T outside the image is zero: see the fp32 head).
+// LDS: 12 rows x 128 cols x 16 ci per chunk as two planes [k half][pixel][16 B] (49,152 B),
+// re-used for T (4 x 128 x 29 floats = 59,392 B) in the epilogue.
 // =========================================================================================
-constexpr int HB_ROWS = 12, HB_COLS = 160, HB_PLANE = HB_ROWS * HB_COLS * 16;
+constexpr int HB_ROWS = 12, HB_COLS = 128, HB_MT = HB_COLS / 32, HB_PLANE = HB_ROWS * HB_COLS * 16;
 constexpr int HB_TS = 29;
-constexpr int HB_LDS_BYTES = 4 * HB_COLS * HB_TS * 4;     // 74,240 >= 2*HB_PLANE = 61,440
+constexpr int HB_LDS_BYTES = 4 * HB_COLS * HB_TS * 4;     // 59,392 >= 2*HB_PLANE = 49,152
+constexpr int HB_PIECES = HB_ROWS * HB_COLS * 2 / 256;    // 16-byte pieces per thread and chunk: 12
 
 __global__ __launch_bounds__(256, 2) void head_bf16_kernel(HeadArgs a)
 {
@@ -254,36 +256,37 @@ __global__ __launch_bounds__(256, 2) void head_bf16_kernel(HeadArgs a)
     const __bf16* in = (const __bf16*)a.in + (size_t)n * kHR * kHR * kC;
     const bf16x8* wp = (const bf16x8*)a.wpack;
 
-    f32x16 acc[5];
+    f32x16 acc[HB_MT];
 #pragma unroll
-    for (int mt = 0; mt < 5; ++mt)
+    for (int mt = 0; mt < HB_MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
 
-    // 12 x 160 pixel halo tile of one 16-ci chunk = 3,840 16-byte pieces, 15 per thread.  The
-    // loads are branch-free (clamped address + a validity bit applied at the LDS store) and are
+    // 12 x 128 pixel tile (row halo only) of one 16-ci chunk = 3,072 16-byte pieces, 12 per thread.  The
+    // loads are branch-free (clamped row + a validity bit applied at the LDS store) and are
     // issued one chunk ahead, so their latency sits under the previous chunk's MFMAs.
-    u32x4 stage[15];
+    u32x4 stage[HB_PIECES];
     unsigned ok_bits = 0;
 #pragma unroll
-    for (int it = 0; it < 15; ++it) {
+    for (int it = 0; it < HB_PIECES; ++it) {
         const int i = tid + it * 256, pix = i >> 1;
         const int r = pix / HB_COLS, c = pix - r * HB_COLS;
-        const int gy = y0 - 4 + r, gx = c - 4;
-        ok_bits |= (((unsigned)gy < (unsigned)kHR && (unsigned)gx < (unsigned)kHR) ? 1u : 0u) << it;
+        const int gy = y0 - 4 + r;
+        (void)c;
+        ok_bits |= ((unsigned)gy < (unsigned)kHR ? 1u : 0u) << it;
     }
     auto load_stage = [&](int g) {
 #pragma unroll
-        for (int it = 0; it < 15; ++it) {
+        for (int it = 0; it < HB_PIECES; ++it) {
             const int i = tid + it * 256, half = i & 1, pix = i >> 1;
             const int r = pix / HB_COLS, c = pix - r * HB_COLS;
-            const int cy = min(max(y0 - 4 + r, 0), kHR - 1), cx = min(max(c - 4, 0), kHR - 1);
+            const int cy = min(max(y0 - 4 + r, 0), kHR - 1), cx = c;
             stage[it] = *(const u32x4*)(in + ((size_t)cy * kHR + cx) * kC + g * 16 + half * 8);
         }
     };
     auto store_stage = [&]() {
 #pragma unroll
-        for (int it = 0; it < 15; ++it) {
+        for (int it = 0; it < HB_PIECES; ++it) {
             const int i = tid + it * 256, half = i & 1, pix = i >> 1;
             u32x4 v = stage[it];
             if (!((ok_bits >> it) & 1u)) v = u32x4{0u, 0u, 0u, 0u};
@@ -302,28 +305,28 @@ __global__ __launch_bounds__(256, 2) void head_bf16_kernel(HeadArgs a)
         __syncthreads();
         if (g + 1 < 6) load_stage(g + 1);
         const char* ab = lds + h * HB_PLANE + (w * HB_COLS + p) * 16;
-        bf16x8 a0[5], a1[5];
+        bf16x8 a0[HB_MT], a1[HB_MT];
 #pragma unroll
-        for (int mt = 0; mt < 5; ++mt) a0[mt] = *(const bf16x8*)(ab + 32 * 16 * mt);
+        for (int mt = 0; mt < HB_MT; ++mt) a0[mt] = *(const bf16x8*)(ab + 32 * 16 * mt);
 #pragma unroll
         for (int ky = 0; ky < 9; ++ky) {
             if (ky + 1 < 9) {
 #pragma unroll
-                for (int mt = 0; mt < 5; ++mt) {
+                for (int mt = 0; mt < HB_MT; ++mt) {
                     const bf16x8 v = *(const bf16x8*)(ab + ((ky + 1) * HB_COLS + 32 * mt) * 16);
                     if (ky & 1) a0[mt] = v; else a1[mt] = v;
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int mt = 0; mt < 5; ++mt) acc[mt] = MFMA_BF16((ky & 1) ? a1[mt] : a0[mt], bv[ky], acc[mt]);
+            for (int mt = 0; mt < HB_MT; ++mt) acc[mt] = MFMA_BF16((ky & 1) ? a1[mt] : a0[mt], bv[ky], acc[mt]);
         }
     }
     __syncthreads();
     float* Tl = (float*)lds + w * HB_COLS * HB_TS;
     if (p < 27) {
 #pragma unroll
-        for (int mt = 0; mt < 5; ++mt)
+        for (int mt = 0; mt < HB_MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) Tl[(32 * mt + acc_row(r, h)) * HB_TS + p] = acc[mt][r];
     }
@@ -335,7 +338,10 @@ __global__ __launch_bounds__(256, 2) void head_bf16_kernel(HeadArgs a)
             const int co = i / kOut, x = i - co * kOut;
             float s = a.bias[co];
 #pragma unroll
-            for (int kx = 0; kx < 9; ++kx) s += Tl[(x + kx) * HB_TS + kx * 3 + co];
+            for (int kx = 0; kx < 9; ++kx) {
+                const int xs = x + kx - 4;                   // x' of this tap; outside the image T is zero
+                if ((unsigned)xs < (unsigned)HB_COLS) s += Tl[xs * HB_TS + kx * 3 + co];
+            }
             yo[((size_t)co * kOut + y) * kOut + x] = (__bf16)s;
         }
     }

@@ -173,13 +173,16 @@ hipError_t launch_chan_attn_f32(const ChanAttnArgs& a, hipStream_t s)
 //   out[y][x][co]     = bias[co] + sum_kx T[y][x+kx-4][kx*3+co]
 // i.e. a GEMM with K = 9*96 followed by a 9-term shifted sum done through LDS.  Same FLOPs
 // as the direct form, 84 % of the MFMA columns useful.  Wave w owns output row y0+w and
-// x' in [-4, 156) as five 32-wide M tiles.  Only rows/cols < 125 are stored.
-// LDS: 12 rows x 160 cols x 8 ci per chunk as 4 planes [ci pair][pixel][2]  (61,440 B);
-// re-used for T (4 x 160 x 29 floats = 74,240 B) in the epilogue.
+// x' in [0, 128) as four 32-wide M tiles: T at x' outside the image is identically zero (the
+// input there is the conv's zero padding), so those columns are neither staged nor multiplied --
+// the shifted sum simply skips them.  Only rows/cols < 125 are stored.
+// LDS: 12 rows x 128 cols x 8 ci per chunk as 4 planes [ci pair][pixel][2]  (49,152 B);
+// re-used for T (4 x 128 x 29 floats = 59,392 B) in the epilogue.
 // =========================================================================================
-constexpr int TH_ROWS = 12, TH_COLS = 160, TH_PLANE = TH_ROWS * TH_COLS * 2;
+constexpr int TH_ROWS = 12, TH_COLS = 128, TH_MT = TH_COLS / 32, TH_PLANE = TH_ROWS * TH_COLS * 2;
 constexpr int TH_TS = 29;                       // T row stride (odd: conflict-free reads)
-constexpr int TH_LDS_BYTES = 4 * TH_COLS * TH_TS * 4;   // 74,240 >= 4*TH_PLANE*4 = 61,440
+constexpr int TH_LDS_BYTES = 4 * TH_COLS * TH_TS * 4;   // 59,392 >= 4*TH_PLANE*4 = 49,152
+constexpr int TH_PIECES = TH_ROWS * TH_COLS * 2 / 256;  // 16-byte pieces per thread and chunk: 12
 
 __global__ __launch_bounds__(256, 2) void head_f32_kernel(HeadArgs a)
 {
@@ -195,35 +198,36 @@ __global__ __launch_bounds__(256, 2) void head_f32_kernel(HeadArgs a)
     const float* in = (const float*)a.in + (size_t)n * kHR * kHR * kC;
     const f32x2* wp = (const f32x2*)a.wpack;
 
-    f32x16 acc[5];
+    f32x16 acc[TH_MT];
 #pragma unroll
-    for (int mt = 0; mt < 5; ++mt)
+    for (int mt = 0; mt < TH_MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
 
-    // 12 x 160 pixels x 8 ci per chunk = 3,840 16-byte pieces, 15 per thread; branch-free loads
-    // (clamped address, validity bit applied at the LDS store) issued one chunk ahead.
-    f32x4 stage[15];
+    // 12 x 128 pixels x 8 ci per chunk = 3,072 16-byte pieces, 12 per thread; branch-free loads
+    // (clamped row, validity bit applied at the LDS store) issued one chunk ahead.
+    f32x4 stage[TH_PIECES];
     unsigned ok_bits = 0;
 #pragma unroll
-    for (int it = 0; it < 15; ++it) {
+    for (int it = 0; it < TH_PIECES; ++it) {
         const int i = tid + it * 256, pix = i >> 1;
         const int r = pix / TH_COLS, c = pix - r * TH_COLS;
-        const int gy = y0 - 4 + r, gx = c - 4;
-        ok_bits |= (((unsigned)gy < (unsigned)kHR && (unsigned)gx < (unsigned)kHR) ? 1u : 0u) << it;
+        const int gy = y0 - 4 + r;
+        (void)c;
+        ok_bits |= ((unsigned)gy < (unsigned)kHR ? 1u : 0u) << it;
     }
     auto load_stage = [&](int c8) {
 #pragma unroll
-        for (int it = 0; it < 15; ++it) {
+        for (int it = 0; it < TH_PIECES; ++it) {
             const int i = tid + it * 256, half = i & 1, pix = i >> 1;
             const int r = pix / TH_COLS, c = pix - r * TH_COLS;
-            const int cy = min(max(y0 - 4 + r, 0), kHR - 1), cx = min(max(c - 4, 0), kHR - 1);
+            const int cy = min(max(y0 - 4 + r, 0), kHR - 1), cx = c;
             stage[it] = *(const f32x4*)(in + ((size_t)cy * kHR + cx) * kC + c8 * 8 + half * 4);
         }
     };
     auto store_stage = [&]() {
 #pragma unroll
-        for (int it = 0; it < 15; ++it) {
+        for (int it = 0; it < TH_PIECES; ++it) {
             const int i = tid + it * 256, half = i & 1, pix = i >> 1;
             f32x4 v = stage[it];
             if (!((ok_bits >> it) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -243,11 +247,11 @@ __global__ __launch_bounds__(256, 2) void head_f32_kernel(HeadArgs a)
         store_stage();
         __syncthreads();
         if (c8 + 1 < 12) load_stage(c8 + 1);
-        f32x2 a0[5], a1[5];
+        f32x2 a0[TH_MT], a1[TH_MT];
         {
             const float* ab = smem + h * TH_PLANE + (w * TH_COLS + p) * 2;
 #pragma unroll
-            for (int mt = 0; mt < 5; ++mt) a0[mt] = *(const f32x2*)(ab + 64 * mt);
+            for (int mt = 0; mt < TH_MT; ++mt) a0[mt] = *(const f32x2*)(ab + 64 * mt);
         }
 #pragma unroll
         for (int s = 0; s < 18; ++s) {                // s = ky*2 + u
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(256, 2) void head_f32_kernel(HeadArgs a)
                 const int ky = (s + 1) >> 1, u = (s + 1) & 1;
                 const float* ab = smem + (2 * u + h) * TH_PLANE + ((w + ky) * TH_COLS + p) * 2;
 #pragma unroll
-                for (int mt = 0; mt < 5; ++mt) {
+                for (int mt = 0; mt < TH_MT; ++mt) {
                     const f32x2 v = *(const f32x2*)(ab + 64 * mt);
                     if (s & 1) a0[mt] = v; else a1[mt] = v;
                 }
@@ -264,16 +268,16 @@ __global__ __launch_bounds__(256, 2) void head_f32_kernel(HeadArgs a)
 #pragma unroll
             for (int e = 0; e < 2; ++e)
 #pragma unroll
-                for (int mt = 0; mt < 5; ++mt)
+                for (int mt = 0; mt < TH_MT; ++mt)
                     acc[mt] = MFMA_F32((s & 1) ? a1[mt][e] : a0[mt][e], bv[s][e], acc[mt]);
         }
     }
     __syncthreads();
-    // T -> LDS: Tl[w][x' index 0..159][n 0..28]
+    // T -> LDS: Tl[w][x' 0..127][n 0..28]
     float* Tl = smem + w * TH_COLS * TH_TS;
     if (p < 27) {
 #pragma unroll
-        for (int mt = 0; mt < 5; ++mt)
+        for (int mt = 0; mt < TH_MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) Tl[(32 * mt + acc_row(r, h)) * TH_TS + p] = acc[mt][r];
     }
@@ -285,7 +289,10 @@ __global__ __launch_bounds__(256, 2) void head_f32_kernel(HeadArgs a)
             const int co = i / kOut, x = i - co * kOut;
             float s = a.bias[co];
 #pragma unroll
-            for (int kx = 0; kx < 9; ++kx) s += Tl[(x + kx) * TH_TS + kx * 3 + co];
+            for (int kx = 0; kx < 9; ++kx) {
+                const int xs = x + kx - 4;                   // x' of this tap; outside the image T is zero
+                if ((unsigned)xs < (unsigned)TH_COLS) s += Tl[xs * TH_TS + kx * 3 + co];
+            }
             yo[((size_t)co * kOut + y) * kOut + x] = s;
         }
     }
