@@ -157,6 +157,17 @@ SRGEN_API int srgen_metrics_scratch_bytes(int n, int c, int hgt, int wid, size_t
 SRGEN_API int srgen_metrics(const float* sr, const float* hr, int n, int c, int hgt, int wid,
                   float* out3, void* scratch, size_t scratch_bytes, void* stream);
 
+/* No counterpart in the reference.  srgen_metrics for callers that cannot allocate device memory (code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc): identical kernels and results, but the
+ * per-tile partial sums live in a file-scope __device__ array inside the library (768 KiB per GPU, held until the
+ * process ends) instead of a caller-provided scratch buffer.  Runs on the CURRENT device; calls no hipMalloc /
+ * hipFree.  Limit: n * c * ceil(hgt/32) * ceil(wid/32) <= SRGEN_METRICS_NOALLOC_MAX_TILES (a 256 x 3 x 125 x 125
+ * batch is 12,288), larger shapes -> SRGEN_E_WORKSPACE.  Every call on one GPU shares that array: calls that
+ * overlap on one GPU (two streams, two threads) race -- serialise them on one stream. */
+#define SRGEN_METRICS_NOALLOC_MAX_TILES 65536
+SRGEN_API int srgen_metrics_noalloc(const float* sr, const float* hr, int n, int c, int hgt, int wid,
+                                    float* out3, void* stream);
+
 /* Replaces: the pixel terms of the training losses (train.py:94 and :170-172): weighted_l1(sr, hr)
  * (train.py:18-20: mean of |sr - hr| weighted 10 where hr > 0.01, 1 elsewhere) next to ssim(sr, hr).
  * Same pass, arguments and scratch as srgen_metrics; out4 = {psnr, ssim, l1, weighted_l1}.

@@ -70,6 +70,8 @@ def lib() -> ctypes.CDLL:
     L.srgen_normalize.argtypes = [vp, vp, sz, ctypes.c_float, i, vp]
     L.srgen_metrics_scratch_bytes.argtypes = [i, i, i, i, ctypes.POINTER(sz)]
     L.srgen_metrics.argtypes = [vp, vp, i, i, i, i, vp, vp, sz, vp]
+    L.srgen_metrics_noalloc.argtypes = [vp, vp, i, i, i, i, vp, vp]
+    L.srgen_metrics_noalloc.restype = i
     L.srgen_pixel_losses.argtypes = [vp, vp, i, i, i, i, vp, vp, sz, vp]
     L.srgen_pixel_losses.restype = i
     L.srdisc_create.argtypes = [ctypes.POINTER(srdisc_config), ctypes.POINTER(vp)]

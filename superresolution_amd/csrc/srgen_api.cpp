@@ -811,6 +811,22 @@ int srgen_metrics(const float* sr, const float* hr, int n, int c, int hgt, int w
     return run_metrics(sr, hr, n, c, hgt, wid, out3, 3, scratch, scratch_bytes, stream);
 }
 
+int srgen_metrics_noalloc(const float* sr, const float* hr, int n, int c, int hgt, int wid, float* out3, void* stream)
+{
+    if (!sr || !hr || !out3) return fail(SRGEN_E_INVALID, "NULL argument");
+    if (n <= 0 || c <= 0 || hgt <= 0 || wid <= 0) return fail(SRGEN_E_INVALID, "bad metrics shape");
+    const long long tiles = (long long)n * c * ((hgt + 31) / 32) * ((wid + 31) / 32);
+    if (tiles > kMetricsStaticMaxTiles)
+        return fail(SRGEN_E_WORKSPACE,
+                    "srgen_metrics_noalloc: %lld tiles of 32x32 over (n=%d, c=%d, %dx%d) exceed the static scratch "
+                    "of %d tiles; use srgen_metrics with a caller-provided scratch buffer",
+                    tiles, n, c, hgt, wid, kMetricsStaticMaxTiles);
+    float* partials = nullptr;
+    HIP_TRY(metrics_static_scratch(&partials));        // per-device address of the library's __device__ array
+    HIP_TRY(launch_metrics(sr, hr, n, c, hgt, wid, out3, partials, 3, (hipStream_t)stream));
+    return SRGEN_OK;
+}
+
 int srgen_pixel_losses(const float* sr, const float* hr, int n, int c, int hgt, int wid, float* out4,
                        void* scratch, size_t scratch_bytes, void* stream)
 {

@@ -107,6 +107,12 @@ size_t metrics_scratch_bytes(int n, int c, int h, int w, int nout);
 hipError_t launch_metrics(const float* sr, const float* hr, int n, int c, int h, int w,
                           float* out, void* scratch, int nout, hipStream_t s);
 
+// srgen_metrics_noalloc: per-tile partial sums in a file-scope __device__ array of the library (srgen_kernels_misc.hip)
+constexpr int kMetricsStaticMaxTiles = 65536;        // 32x32 tiles over all (n, c) planes: 768 KiB of partials
+int metrics_tiles(int n, int c, int h, int w);
+// device address of that array on the CURRENT device (hipGetSymbolAddress once per device); allocates nothing
+hipError_t metrics_static_scratch(float** ptr);
+
 // ---- discriminator (Discriminator.py:17-50): NHWC fp32 activations (srdisc_kernels.hip) ---------
 struct DiscStemArgs {          // conv 3 -> 64, stride 1, pad 1, + LeakyReLU
     const float* x;            // (N,3,H,W) NCHW

@@ -2,6 +2,8 @@
 // bilinear resize, and the validate() metrics (PSNR / SSIM / L1).
 #include "srgen_internal.h"
 
+#include <mutex>
+
 namespace srgen {
 
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short b)
@@ -268,6 +270,40 @@ hipError_t launch_metrics(const float* sr, const float* hr, int n, int c, int h,
 {
     return nout == 4 ? launch_metrics_n<4>(sr, hr, n, c, h, w, out, scratch, s)
                      : launch_metrics_n<3>(sr, hr, n, c, h, w, out, scratch, s);
+}
+
+// ---- srgen_metrics_noalloc: the same two kernels with the per-tile partial sums in a file-scope device array ----
+// For callers that cannot allocate (HIP graph capture, tight serving loops).  `metrics_static_partials` is a
+// host-side stand-in here, NOT a device address: the per-device address comes from hipGetSymbolAddress, once per
+// device with that device current (every GPU holds its own copy at its own address), and only that pointer is ever
+// handed to a kernel.  Every tile kernel writes its partial before the final kernel reads it, so nothing in the
+// array has to start at zero; every call on one GPU shares the array, so calls that overlap on one GPU race.
+static __device__ __align__(256) float metrics_static_partials[(size_t)kMetricsStaticMaxTiles * 3];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_static_mu;
+float* g_static_ptr[kMaxDevices] = {};
+}  // namespace
+
+int metrics_tiles(int n, int c, int h, int w) { return metric_blocks(n, c, h, w); }
+
+hipError_t metrics_static_scratch(float** ptr)
+{
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_static_mu);
+    if (!g_static_ptr[dev]) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(metrics_static_partials));
+        if (e != hipSuccess) return e;
+        if (!p) return hipErrorInvalidSymbol;
+        g_static_ptr[dev] = static_cast<float*>(p);
+    }
+    *ptr = g_static_ptr[dev];
+    return hipSuccess;
 }
 
 // ---- train-mode BatchNorm (nn.BatchNorm2d in .train(), Generator.py:35,38,63) over NHWC (P, 96) fp32 ------
