@@ -117,6 +117,8 @@ def main():
     ap.add_argument("--cfg2-reps", type=int, default=5)
     ap.add_argument("--median-steps", type=int, default=50, help="HIP-event-timed steps of the median leg (>= 50)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lean", action="store_true", help="profiling runs (rocprofv3): only the K timed steps of --dtype and "
+                    "the per-kernel HIP-event leg; the line then carries no bf16 / cfg2 / psnr / hbm objects")
     ap.add_argument("--dry-run", action="store_true", help="ranks report their rendezvous environment and exit "
                     "(launcher rehearsal on a box without GPUs)")
     args = ap.parse_args()
@@ -296,6 +298,20 @@ def main():
 
     # ---- legs ---------------------------------------------------------------------------------------------
     dt_main = timed_forward(dtype, args.steps, args.warmup)
+    if args.lean:
+        if rank == 0:
+            kern = kernel_profile(dtype)
+            v = args.batch * n_ranks * args.steps / dt_main
+            print(json.dumps({"metric": "generator images/s (64x64->125x125)", "value": round(v, 2), "unit": "images/s",
+                              "n_gpus": n_ranks, "steps": args.steps, "warmup": args.warmup,
+                              "ms_per_step": round(dt_main / args.steps * 1e3, 3), "higher_is_better": True,
+                              "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+                              "config": {"workload": f"lean profiling run of the cfg1 leg, batch {args.batch}, {dtype}"},
+                              "roofline": roofline(dtype, kern), "kernels": kern}), flush=True)
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     med = median_forward(dtype, max(50, args.median_steps), min_seconds=4.0 if world == 1 else 0.0)
     other = "bf16" if dtype == "f32" else "f32"
     dt_other = timed_forward(other, max(20, args.steps // 2), 3)
