@@ -175,6 +175,59 @@ SRGEN_API int srgen_metrics_noalloc(const float* sr, const float* hr, int n, int
 SRGEN_API int srgen_pixel_losses(const float* sr, const float* hr, int n, int c, int hgt, int wid,
                                  float* out4, void* scratch, size_t scratch_bytes, void* stream);
 
+/* ---- Pre-train step operators (backward pass + optimizer) -------------------------------------------------
+ * SURVEY.md 8(f) "next" row 2: what autograd and torch.optim.AdamW do for the reference's pre-train step
+ * (train.py:90-97: loss.backward(), optimizer.step(); train.py:270: AdamW(lr 1e-4, default weight decay 0.01)),
+ * as operators on fp32 NHWC activations (n, hw, hw, 96).  First slice: everything the residual trunk
+ * (Generator.py:30-42: conv3x3 -> BatchNorm -> PReLU -> conv3x3 -> BatchNorm, x + 0.1 * block) and the pixel losses
+ * need; superresolution_amd/training.py composes them.  All pointers are device pointers; nothing synchronises. */
+
+/* Replaces: the weight side of F.conv2d(x, w, padding=1) and of its data gradient.  Forms the Winograd weight image
+ * the 3x3 kernel reads (U = G g Gt, fp64 on the device, rounded once) from OIHW fp32 weights that change every step.
+ *   mode 0: forward image of a (cout_total, 96, 3, 3) weight; cout_total = 96, or 384 with the PixelShuffle channel
+ *           permutation of Generator.py:7-8 (out: cout_total/96 * 16*96*96 floats)
+ *   mode 1: image of the data-gradient conv of cout block `block` (transposed, flipped taps; out: 16*96*96 floats) */
+SRGEN_API int srgen_wino_pack(const float* w_oihw, int cout_total, int mode, int block, float* out, void* stream);
+
+/* Replaces: F.conv2d(x, w, b, padding=1) on NHWC tensors (Generator.py:34,37,62 in train mode, where no BatchNorm can
+ * be folded), and -- with a mode-1 image and bias NULL -- its data gradient.  out = conv(x) + bias [+ res].
+ * hw 64 (cout_blocks 1, or 4 with shuffle = 1: the PixelShuffle(2) store) or hw 128 (cout_blocks 1).
+ * The first call on a device allocates 26 KB of constants (hipMalloc) that stay until the process ends. */
+SRGEN_API int srgen_conv3x3_nhwc(const float* x, const float* wpack, const float* bias, const float* res, float* out,
+                                 int n, int hw, int cout_blocks, int shuffle, void* stream);
+
+/* Replaces: the weight / bias gradient of F.conv2d(x, w, b, padding=1): dw (96, 96, 3, 3) OIHW =
+ * sum over pixels dy[n,y,x,co] * x[n,y+ky-1,x+kx-1,ci]; dbias [96] = sum dy (NULL to skip).  Fixed summation order. */
+SRGEN_API int srgen_conv3x3_wgrad_scratch_bytes(int n, int hw, size_t* bytes);
+SRGEN_API int srgen_conv3x3_wgrad(const float* x, const float* dy, int n, int hw, float* dw, float* dbias,
+                                  void* scratch, size_t scratch_bytes, void* stream);
+
+/* Replaces: nn.BatchNorm2d(96) in train mode (+ PReLU(96), + the residual add) forward and backward
+ * (Generator.py:35-36,38,42).  c: conv output (npix, 96), kept for the backward.
+ *   fwd: out = res + res_factor * PReLU_slope(bn(c))   (slope / res may be NULL; out may alias c);
+ *        batch_stats [2][96] = {batch mean, biased batch variance} (the caller applies the running-stat update)
+ *   bwd: given dout = d/d(PReLU(bn(c))), scaled by dout_scale (the 0.1 of the residual branch):
+ *        dc, dgamma [96], dbeta [96], dslope [96] (iff slope) */
+SRGEN_API int srgen_bn_train_scratch_bytes(size_t* bytes);
+SRGEN_API int srgen_bn_train_fwd(const float* c, float* out, const float* gamma, const float* beta, const float* slope,
+                                 const float* res, float res_factor, float* batch_stats, size_t npix, void* scratch,
+                                 size_t scratch_bytes, void* stream);
+SRGEN_API int srgen_bn_train_bwd(const float* c, const float* dout, const float* batch_stats, const float* gamma,
+                                 const float* beta, const float* slope, float dout_scale, float* dc, float* dgamma,
+                                 float* dbeta, float* dslope, size_t npix, void* scratch, size_t scratch_bytes,
+                                 void* stream);
+
+/* Replaces: autograd through the pre-train loss (train.py:93): dsr = d/dsr [w_l1 * weighted_l1(sr, hr) +
+ * w_ssim * (1 - ssim(sr, hr))] (train.py:18-20; utils.py:21-41), sr / hr / dsr (n, c, hgt, wid) NCHW fp32.
+ * scratch: 3 * n*c*hgt*wid floats. */
+SRGEN_API int srgen_pixel_loss_grad(const float* sr, const float* hr, int n, int c, int hgt, int wid, float w_l1,
+                                    float w_ssim, float* dsr, void* scratch, size_t scratch_bytes, void* stream);
+
+/* Replaces: torch.optim.AdamW.step() (train.py:97,270) over one flat fp32 buffer: decoupled weight decay,
+ * bias-corrected first / second moments; step counts from 1. */
+SRGEN_API int srgen_adamw(float* p, const float* g, float* m, float* v, size_t numel, float lr, float beta1,
+                          float beta2, float eps, float weight_decay, int step, void* stream);
+
 /* ---- Discriminator + relativistic-average GAN loss (forward values) ------------------------
  * SURVEY.md 8(f) "next" row 3: the PatchGAN critic the reference's GAN phase evaluates on hr and on
  * generator output (train.py:145-176).  Same conventions as above; fp32 only.  These entry points

@@ -81,6 +81,20 @@ def lib() -> ctypes.CDLL:
     L.srdisc_workspace_bytes.argtypes = [vp, i, i, i, ctypes.POINTER(sz)]
     L.srdisc_forward.argtypes = [vp, vp, vp, vp, sz, i, i, i, ctypes.POINTER(vp), vp]
     L.srgen_ragan_loss.argtypes = [vp, vp, sz, sz, ctypes.c_float, ctypes.c_float, vp, vp]
+    f = ctypes.c_float
+    L.srgen_wino_pack.argtypes = [vp, i, i, i, vp, vp]
+    L.srgen_conv3x3_nhwc.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, vp]
+    L.srgen_conv3x3_wgrad_scratch_bytes.argtypes = [i, i, ctypes.POINTER(sz)]
+    L.srgen_conv3x3_wgrad.argtypes = [vp, vp, i, i, vp, vp, vp, sz, vp]
+    L.srgen_bn_train_scratch_bytes.argtypes = [ctypes.POINTER(sz)]
+    L.srgen_bn_train_fwd.argtypes = [vp, vp, vp, vp, vp, vp, f, vp, sz, vp, sz, vp]
+    L.srgen_bn_train_bwd.argtypes = [vp, vp, vp, vp, vp, vp, f, vp, vp, vp, vp, sz, vp, sz, vp]
+    L.srgen_pixel_loss_grad.argtypes = [vp, vp, i, i, i, i, f, f, vp, vp, sz, vp]
+    L.srgen_adamw.argtypes = [vp, vp, vp, vp, sz, f, f, f, f, f, i, vp]
+    for name in ("srgen_wino_pack", "srgen_conv3x3_nhwc", "srgen_conv3x3_wgrad_scratch_bytes", "srgen_conv3x3_wgrad",
+                 "srgen_bn_train_scratch_bytes", "srgen_bn_train_fwd", "srgen_bn_train_bwd", "srgen_pixel_loss_grad",
+                 "srgen_adamw"):
+        getattr(L, name).restype = i
     for name in ("srdisc_create", "srdisc_destroy", "srdisc_set_tensor", "srdisc_commit_weights",
                  "srdisc_workspace_bytes", "srdisc_forward", "srgen_ragan_loss"):
         getattr(L, name).restype = i

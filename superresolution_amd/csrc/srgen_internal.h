@@ -151,8 +151,29 @@ hipError_t launch_ragan_loss(const float* real, const float* fake, size_t n_real
 // the biased batch variance (eps 1e-5); batch_stats receives {mean[96], biased var[96]}.
 constexpr int kBnBlocks = 1024;
 size_t bn_scratch_bytes();
+// out == nullptr: in place; else t stays (the saved conv output of the training step) and out receives the result
 hipError_t launch_bn_train(float* t, size_t npix, const float* gamma, const float* beta, const float* slope,
-                           const float* res, float res_factor, void* scratch, float* batch_stats, hipStream_t s);
+                           const float* res, float res_factor, void* scratch, float* batch_stats, hipStream_t s,
+                           float* out = nullptr);
+
+// ---- backward-pass operators of the pre-train step (srgen_train_kernels.hip) --------------------------------------
+// Winograd weight image formed on the device from OIHW fp32 weights: mode 0 forward (cout_total 96 or 384, the
+// latter with the PixelShuffle channel permutation), mode 1 data gradient of cout block `block`
+hipError_t launch_wino_pack(const float* w, float* out, int cout_total, int mode, int block, hipStream_t s);
+size_t conv3x3_wgrad_scratch_bytes(int n, int h);
+// dw: (96, 96, 3, 3) OIHW; dbias: [96] or nullptr; x, dy: (n, h, h, 96) NHWC
+hipError_t launch_conv3x3_wgrad(const float* x, const float* dy, int n, int h, float* dw, float* dbias, void* scratch,
+                                hipStream_t s);
+size_t bn_bwd_scratch_bytes();
+// c: saved conv output; dt: gradient of the BatchNorm(+PReLU) output (scaled by dscale); stats: {mean, biased var}
+hipError_t launch_bn_train_bwd(const float* c, const float* dt, const float* stats, const float* gamma, const float* beta,
+                               const float* slope, float dscale, float* dc, float* dgamma, float* dbeta, float* dslope,
+                               size_t npix, void* scratch, hipStream_t s);
+// dsr = d/dsr [w_l1 * weighted_l1(sr, hr) + w_ssim * (1 - ssim(sr, hr))]; scratch: 3 * n*c*h*w floats
+hipError_t launch_pixel_loss_grad(const float* sr, const float* hr, int n, int c, int h, int w, float w_l1, float w_ssim,
+                                  float* dsr, void* scratch, hipStream_t s);
+hipError_t launch_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
+                        float wd, int step, hipStream_t s);
 hipError_t launch_pool_partial(const float* t, int n, int hw, int parts, float* pool_partial, hipStream_t s);
 
 // ---- packed-weight geometry shared by the packers (host) and the kernels ---------------

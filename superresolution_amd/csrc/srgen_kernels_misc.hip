@@ -388,7 +388,7 @@ __global__ __launch_bounds__(768) void bn_final_kernel(const double* partial, in
     }
 }
 
-__global__ __launch_bounds__(256) void bn_apply_kernel(float* t, const float* __restrict__ scale_shift,
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* t, float* out, const float* __restrict__ scale_shift,
                                                        const float* __restrict__ slope, const float* __restrict__ res,
                                                        float res_factor, size_t n4)
 {
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(float* t, const float* __
             v.x = fmaf(res_factor, v.x, r.x); v.y = fmaf(res_factor, v.y, r.y);
             v.z = fmaf(res_factor, v.z, r.z); v.w = fmaf(res_factor, v.w, r.w);
         }
-        *reinterpret_cast<float4*>(t + i * 4) = v;
+        *reinterpret_cast<float4*>(out + i * 4) = v;
     }
 }
 
@@ -440,8 +440,9 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(const float* __restri
 size_t bn_scratch_bytes() { return (size_t)kBnBlocks * 192 * sizeof(double) + 2 * 96 * sizeof(float); }
 
 hipError_t launch_bn_train(float* t, size_t npix, const float* gamma, const float* beta, const float* slope,
-                           const float* res, float res_factor, void* scratch, float* batch_stats, hipStream_t s)
+                           const float* res, float res_factor, void* scratch, float* batch_stats, hipStream_t s, float* out)
 {
+    if (!out) out = t;                                   // in place (the forward-values path)
     double* partial = static_cast<double*>(scratch);
     float* ss = reinterpret_cast<float*>(partial + (size_t)kBnBlocks * 192);
     const int nb = npix < (size_t)kBnBlocks * 10 ? (int)((npix + 9) / 10) : kBnBlocks;
@@ -450,7 +451,7 @@ hipError_t launch_bn_train(float* t, size_t npix, const float* gamma, const floa
                        batch_stats);
     const size_t n4 = npix * 24;
     const size_t want = (n4 + 255) / 256;
-    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)(want < 16384 ? want : 16384)), dim3(256), 0, s, t, ss, slope,
+    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)(want < 16384 ? want : 16384)), dim3(256), 0, s, t, out, ss, slope,
                        res, res_factor, n4);
     return hipGetLastError();
 }

@@ -1,0 +1,166 @@
+// srgen_train_api.cpp -- C ABI of the training-step operators (include/srgen.h, "pre-train step" section):
+// what autograd + torch.optim.AdamW do for the reference at /root/reference/train.py:90-97,270, for the residual
+// trunk of the generator (Generator.py:30-42) and the pixel losses (train.py:18-20,93; utils.py:21-41).
+#include "../../include/srgen.h"
+#include "srgen_internal.h"
+
+#include <mutex>
+#include <vector>
+
+using namespace srgen;
+
+namespace {
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail(SRGEN_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                               \
+    } while (0)
+
+// Per-device constants the Winograd conv kernel wants beside its operands: a zero page (source of out-of-image halo
+// rows, and the bias of a bias-free conv) followed by 384 ones (identity PReLU slope: the raw conv output).
+// Allocated once per device on first use and kept until the process ends.
+constexpr size_t kOnesOff = kWinoZeroBytes;
+constexpr size_t kConstBytes = kWinoZeroBytes + 384 * sizeof(float);
+std::mutex g_mu;
+char* g_consts[64] = {};
+
+int train_consts(const char** out)
+{
+    int dev = -1;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return fail(SRGEN_E_UNSUPPORTED, "device index %d outside [0, 64)", dev);
+    std::lock_guard<std::mutex> lock(g_mu);
+    if (!g_consts[dev]) {
+        char* p = nullptr;
+        HIP_TRY(hipMalloc((void**)&p, kConstBytes));
+        std::vector<float> host(kConstBytes / sizeof(float), 0.f);
+        for (size_t i = kOnesOff / sizeof(float); i < host.size(); ++i) host[i] = 1.f;
+        hipError_t e = hipMemcpy(p, host.data(), kConstBytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(p);
+            return fail(SRGEN_E_HIP, "hipMemcpy of the train constants failed: %s", hipGetErrorString(e));
+        }
+        g_consts[dev] = p;
+    }
+    *out = g_consts[dev];
+    return SRGEN_OK;
+}
+
+inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+int srgen_wino_pack(const float* w_oihw, int cout_total, int mode, int block, float* out, void* stream)
+{
+    if (!w_oihw || !out) return fail(SRGEN_E_INVALID, "NULL argument");
+    if (cout_total != 96 && cout_total != 384) return fail(SRGEN_E_UNSUPPORTED, "cout %d: 96 or 384", cout_total);
+    if (mode != 0 && mode != 1) return fail(SRGEN_E_INVALID, "mode %d: 0 forward, 1 data gradient", mode);
+    if (block < 0 || block >= cout_total / 96) return fail(SRGEN_E_INVALID, "block %d outside [0, %d)", block, cout_total / 96);
+    HIP_TRY(launch_wino_pack(w_oihw, out, cout_total, mode, block, (hipStream_t)stream));
+    return SRGEN_OK;
+}
+
+int srgen_conv3x3_nhwc(const float* x, const float* wpack, const float* bias, const float* res, float* out, int n, int hw,
+                       int cout_blocks, int shuffle, void* stream)
+{
+    if (!x || !wpack || !out) return fail(SRGEN_E_INVALID, "NULL argument");
+    if (n <= 0) return fail(SRGEN_E_INVALID, "batch %d", n);
+    if (!((hw == kLR && cout_blocks == 1 && !shuffle) || (hw == kLR && cout_blocks == 4 && shuffle && !res) ||
+          (hw == kHR && cout_blocks == 1 && !shuffle && !res)))
+        return fail(SRGEN_E_UNSUPPORTED, "conv3x3 shape (hw %d, cout blocks %d, shuffle %d, residual %d) has no kernel", hw,
+                    cout_blocks, shuffle, res != nullptr);
+    if (!aligned16(x) || !aligned16(wpack) || !aligned16(out) || !aligned16(res))
+        return fail(SRGEN_E_INVALID, "operands must be 16-byte aligned");
+    const char* consts = nullptr;
+    if (int rc = train_consts(&consts)) return rc;
+    Conv3x3Args a;
+    a.in = x; a.out = out; a.wpack = wpack;
+    a.zeros = consts;
+    a.bias = bias ? bias : (const float*)consts;                          // bias-free: the zero page
+    a.slope = res ? nullptr : (const float*)(consts + kOnesOff);          // identity PReLU = the raw conv output
+    a.res = res; a.pool_partial = nullptr;
+    a.N = n; a.H = hw; a.W = hw; a.cout_blocks = cout_blocks; a.shuffle = shuffle;
+    HIP_TRY(launch_conv3x3_f32_wino(a, (hipStream_t)stream));
+    return SRGEN_OK;
+}
+
+int srgen_conv3x3_wgrad_scratch_bytes(int n, int hw, size_t* bytes)
+{
+    if (!bytes || n <= 0 || hw <= 0) return fail(SRGEN_E_INVALID, "bad argument");
+    *bytes = (conv3x3_wgrad_scratch_bytes(n, hw) + 255) & ~(size_t)255;
+    return SRGEN_OK;
+}
+
+int srgen_conv3x3_wgrad(const float* x, const float* dy, int n, int hw, float* dw, float* dbias, void* scratch,
+                        size_t scratch_bytes, void* stream)
+{
+    if (!x || !dy || !dw || !scratch) return fail(SRGEN_E_INVALID, "NULL argument");
+    if (n <= 0 || hw <= 0 || (hw & 3)) return fail(SRGEN_E_INVALID, "bad shape (n %d, hw %d: a multiple of 4)", n, hw);
+    if (scratch_bytes < conv3x3_wgrad_scratch_bytes(n, hw)) return fail(SRGEN_E_WORKSPACE, "wgrad scratch too small");
+    HIP_TRY(launch_conv3x3_wgrad(x, dy, n, hw, dw, dbias, scratch, (hipStream_t)stream));
+    return SRGEN_OK;
+}
+
+int srgen_bn_train_scratch_bytes(size_t* bytes)
+{
+    if (!bytes) return fail(SRGEN_E_INVALID, "bytes is NULL");
+    const size_t a = bn_scratch_bytes(), b = bn_bwd_scratch_bytes();
+    *bytes = ((a > b ? a : b) + 255) & ~(size_t)255;
+    return SRGEN_OK;
+}
+
+int srgen_bn_train_fwd(const float* c, float* out, const float* gamma, const float* beta, const float* slope,
+                       const float* res, float res_factor, float* batch_stats, size_t npix, void* scratch,
+                       size_t scratch_bytes, void* stream)
+{
+    if (!c || !out || !gamma || !beta || !batch_stats || !scratch) return fail(SRGEN_E_INVALID, "NULL argument");
+    if (npix == 0) return fail(SRGEN_E_INVALID, "empty batch");
+    if (scratch_bytes < bn_scratch_bytes()) return fail(SRGEN_E_WORKSPACE, "BatchNorm scratch too small");
+    if (!aligned16(c) || !aligned16(out) || !aligned16(res)) return fail(SRGEN_E_INVALID, "operands must be 16-byte aligned");
+    HIP_TRY(launch_bn_train(const_cast<float*>(c), npix, gamma, beta, slope, res, res_factor, scratch, batch_stats,
+                            (hipStream_t)stream, out));
+    return SRGEN_OK;
+}
+
+int srgen_bn_train_bwd(const float* c, const float* dout, const float* batch_stats, const float* gamma, const float* beta,
+                       const float* slope, float dout_scale, float* dc, float* dgamma, float* dbeta, float* dslope,
+                       size_t npix, void* scratch, size_t scratch_bytes, void* stream)
+{
+    if (!c || !dout || !batch_stats || !gamma || !beta || !dc || !dgamma || !dbeta || !scratch)
+        return fail(SRGEN_E_INVALID, "NULL argument");
+    if (slope && !dslope) return fail(SRGEN_E_INVALID, "slope without dslope");
+    if (npix == 0) return fail(SRGEN_E_INVALID, "empty batch");
+    if (scratch_bytes < bn_bwd_scratch_bytes()) return fail(SRGEN_E_WORKSPACE, "BatchNorm scratch too small");
+    if (!aligned16(c) || !aligned16(dout) || !aligned16(dc)) return fail(SRGEN_E_INVALID, "operands must be 16-byte aligned");
+    HIP_TRY(launch_bn_train_bwd(c, dout, batch_stats, gamma, beta, slope, dout_scale, dc, dgamma, dbeta, slope ? dslope : nullptr,
+                                npix, scratch, (hipStream_t)stream));
+    return SRGEN_OK;
+}
+
+int srgen_pixel_loss_grad(const float* sr, const float* hr, int n, int c, int hgt, int wid, float w_l1, float w_ssim,
+                          float* dsr, void* scratch, size_t scratch_bytes, void* stream)
+{
+    if (!sr || !hr || !dsr || !scratch) return fail(SRGEN_E_INVALID, "NULL argument");
+    if (n <= 0 || c <= 0 || hgt <= 0 || wid <= 0) return fail(SRGEN_E_INVALID, "bad shape");
+    if (scratch_bytes < (size_t)3 * n * c * hgt * wid * sizeof(float))
+        return fail(SRGEN_E_WORKSPACE, "loss-gradient scratch too small: 3 * n*c*h*w floats");
+    HIP_TRY(launch_pixel_loss_grad(sr, hr, n, c, hgt, wid, w_l1, w_ssim, dsr, scratch, (hipStream_t)stream));
+    return SRGEN_OK;
+}
+
+int srgen_adamw(float* p, const float* g, float* m, float* v, size_t numel, float lr, float beta1, float beta2, float eps,
+                float weight_decay, int step, void* stream)
+{
+    if (numel == 0) return SRGEN_OK;
+    if (!p || !g || !m || !v) return fail(SRGEN_E_INVALID, "NULL argument");
+    if (step < 1) return fail(SRGEN_E_INVALID, "step %d: counts from 1", step);
+    HIP_TRY(launch_adamw(p, g, m, v, numel, lr, beta1, beta2, eps, weight_decay, step, (hipStream_t)stream));
+    return SRGEN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,482 @@
+// srgen_train_kernels.hip -- backward-pass operators of the pre-train step (SURVEY.md 8(f) row 2;
+// /root/reference/train.py:90-97: loss.backward(), optimizer.step() with AdamW, train.py:270), fp32,
+// NHWC activations, for the residual trunk of the generator (Generator.py:30-42):
+//   * device-side Winograd weight images (forward and data-gradient form) -- the weights change every step,
+//     so U = G g Gt is formed on the device, not on the host as srgen_commit_weights does;
+//   * conv3x3 weight gradient on v_mfma_f32_16x16x4_f32 (split over pixel slices, fixed-order reduction);
+//   * train-mode BatchNorm backward with the PReLU backward fused in front of it;
+//   * the gradient of weighted_l1 + w * (1 - ssim) with respect to the generator output (train.py:18-20,93;
+//     utils.py:21-41);
+//   * AdamW (torch.optim.AdamW semantics) over a flat parameter buffer.
+// The data gradient of a 3x3 conv is the forward Winograd kernel (srgen_conv3x3_f32_wino.hip) run on the
+// transposed, flipped weight image made here.
+#include "srgen_internal.h"
+
+namespace srgen {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- Winograd weight image on the device ---------------------------------------------------------------
+// Layout of srgen_conv3x3_f32_wino.hip (srgen_api.cpp pack3x3_wino_f32): float4 units
+// [cb][nu 4][ci chunk 6][xi 4][ci/4 4][co 96], 4 consecutive ci per unit.
+// mode 0 (forward): block b, packed channel co <- original output channel (shuffle ? 4*co + b : 96*b + co).
+// mode 1 (data gradient of block `block`): the conv that maps dY (channels = original output channels of the
+// block) to dX (channels = original input channels): g'[out = ci0][in = co0][r][c] = w[oc(co0)][ci0][2-r][2-c].
+__global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ out, int cb,
+                                                        int shuffle, int mode, int block)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= cb * 96 * 96) return;
+    const int ci = idx % 96, co = (idx / 96) % 96, b = idx / (96 * 96);
+    double g[3][3];
+    if (mode == 0) {
+        const int oc = shuffle ? 4 * co + b : 96 * b + co;
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) g[r][c] = (double)w[((size_t)oc * 96 + ci) * 9 + r * 3 + c];
+    } else {
+        const int oc = shuffle ? 4 * ci + block : 96 * block + ci;       // original output channel = this conv's input
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) g[r][c] = (double)w[((size_t)oc * 96 + co) * 9 + (2 - r) * 3 + (2 - c)];
+    }
+    const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    for (int xi = 0; xi < 4; ++xi)
+        for (int nu = 0; nu < 4; ++nu) {
+            double u = 0;
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) u += G[xi][r] * g[r][c] * G[nu][c];
+            out[((((((size_t)b * 4 + nu) * 6 + ci / 16) * 4 + xi) * 4 + (ci / 4) % 4) * 96 + co) * 4 + (ci & 3)] = (float)u;
+        }
+}
+
+hipError_t launch_wino_pack(const float* w, float* out, int cout_total, int mode, int block, hipStream_t s)
+{
+    const int shuffle = cout_total == 384;
+    const int cb = mode == 0 ? cout_total / 96 : 1;
+    hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)((cb * 96 * 96 + 255) / 256)), dim3(256), 0, s, w, out, cb, shuffle,
+                       mode, block);
+    return hipGetLastError();
+}
+
+// ---- conv3x3 weight gradient ------------------------------------------------------------------------------
+// dW[co][ci][ky][kx] = sum over pixels dY[n][y][x][co] * X[n][y+ky-1][x+kx-1][ci] (zero outside the image).
+// A GEMM with M = co, N = ci, K = pixels per tap.  Workgroup = (tap, slice of image rows), 4 waves as a 2 x 2
+// grid of 48 co x 48 ci (3 x 3 tiles of v_mfma_f32_16x16x4_f32: A = dY^T with lane (i, kq) holding
+// dY[pixel kq][co i], B = X with lane (kq, j) holding X[shifted pixel kq][ci j]; both straight from the NHWC
+// tensors, 64-byte runs per pixel).  Partial sums go to a slab [slice][tap][co][ci]; a second kernel adds the
+// slices in fixed order (bitwise reproducible) and transposes to OIHW.  The centre-tap workgroups also
+// produce the bias gradient sum_pixels dY.
+__global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            int total_rows, int H, int W, int rows_per_slice,
+                                                            float* __restrict__ slab, float* __restrict__ bias_slab)
+{
+    const int tap = blockIdx.x % 9, slice = blockIdx.x / 9;
+    const int ky = tap / 3, kx = tap % 3;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wr = wv >> 1, wc = wv & 1;
+    const int i = lane & 15, kq = lane >> 4;
+    f32x4 acc[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum[3] = {0.f, 0.f, 0.f};
+    const int r0 = slice * rows_per_slice;
+    const int r1 = min(r0 + rows_per_slice, total_rows);
+    for (int row = r0; row < r1; ++row) {
+        const int yy = row % H;                       // row = n * H + y
+        const int ys = yy + ky - 1;
+        if ((unsigned)ys >= (unsigned)H) continue;    // the shifted row lies outside the image: contributes zero
+        const float* dyr = dy + (size_t)row * W * 96 + 48 * wr + i;
+        const float* xr = x + ((size_t)(row + ky - 1) * W + (kx - 1)) * 96 + 48 * wc + i;
+        for (int x0 = 0; x0 < W; x0 += 4) {
+            const int px = x0 + kq;
+            const int xs = px + kx - 1;
+            const bool ok = (unsigned)xs < (unsigned)W;
+            float av[3], bv[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) av[a] = dyr[(size_t)px * 96 + 16 * a];
+#pragma unroll
+            for (int b = 0; b < 3; ++b) bv[b] = ok ? xr[(size_t)px * 96 + 16 * b] : 0.f;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                bsum[a] += av[a];
+#pragma unroll
+                for (int b = 0; b < 3; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+            }
+        }
+    }
+    // D[row = 4*(lane>>4) + r][col = lane & 15]
+    float* o = slab + ((size_t)slice * 9 + tap) * 96 * 96;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                o[(size_t)(48 * wr + 16 * a + 4 * kq + r) * 96 + 48 * wc + 16 * b + i] = acc[a][b][r];
+    if (tap == 4 && wc == 0) {                        // every row is visited by the centre tap (ys = yy)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            float v = bsum[a];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (kq == 0) bias_slab[(size_t)slice * 96 + 48 * wr + 16 * a + i] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const float* __restrict__ slab,
+                                                                   const float* __restrict__ bias_slab, int slices,
+                                                                   float* __restrict__ dw, float* __restrict__ dbias)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;          // over tap * 9216 + co * 96 + ci
+    if (idx < 9 * 96 * 96) {
+        const int tap = idx / 9216, rem = idx % 9216;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int sl = 0;
+        for (; sl + 3 < slices; sl += 4) {
+            s0 += slab[((size_t)sl * 9 + tap) * 9216 + rem];
+            s1 += slab[((size_t)(sl + 1) * 9 + tap) * 9216 + rem];
+            s2 += slab[((size_t)(sl + 2) * 9 + tap) * 9216 + rem];
+            s3 += slab[((size_t)(sl + 3) * 9 + tap) * 9216 + rem];
+        }
+        for (; sl < slices; ++sl) s0 += slab[((size_t)sl * 9 + tap) * 9216 + rem];
+        dw[(size_t)rem * 9 + tap] = (s0 + s1) + (s2 + s3);   // (co * 96 + ci) * 9 + tap: OIHW
+    }
+    if (dbias && idx < 96) {
+        float s = 0.f;
+        for (int sl = 0; sl < slices; ++sl) s += bias_slab[(size_t)sl * 96 + idx];
+        dbias[idx] = s;
+    }
+}
+
+static int wgrad_slices(int total_rows) { return total_rows < 512 ? (total_rows + 3) / 4 : 128; }
+
+size_t conv3x3_wgrad_scratch_bytes(int n, int h)
+{
+    const int slices = wgrad_slices(n * h);
+    return ((size_t)slices * 9 * 9216 + (size_t)slices * 96) * sizeof(float);
+}
+
+hipError_t launch_conv3x3_wgrad(const float* x, const float* dy, int n, int h, float* dw, float* dbias, void* scratch,
+                                hipStream_t s)
+{
+    const int total_rows = n * h;
+    const int slices = wgrad_slices(total_rows);
+    const int rps = (total_rows + slices - 1) / slices;
+    float* slab = (float*)scratch;
+    float* bias_slab = slab + (size_t)slices * 9 * 9216;
+    hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3((unsigned)(slices * 9)), dim3(256), 0, s, x, dy, total_rows, h, h, rps,
+                       slab, bias_slab);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((9 * 9216 + 255) / 256), dim3(256), 0, s, slab, bias_slab, slices,
+                       dw, dbias);
+    return hipGetLastError();
+}
+
+// ---- train-mode BatchNorm backward (+ PReLU backward in front of it) ------------------------------------------
+// Forward (Generator.py:35-36 / :38,42): z = gamma * xhat + beta, xhat = (c - mean) * rstd; t = PReLU(z) or z.
+// Given dt (times dout_scale: the 0.1 of the residual branch), dz = dt * (z >= 0 ? 1 : slope[ch]);
+//   dgamma = sum dz * xhat, dbeta = sum dz, dslope = sum dt * z * [z < 0],
+//   dc = gamma * rstd * (dz - dbeta / m - xhat * dgamma / m)                    (m = pixels per channel).
+// Pass 1: per-channel sums (fp32 inside a thread's run, fp64 across threads and workgroups, fixed order);
+// pass 2 (one workgroup): coefficients; pass 3: apply.  xhat and z are recomputed from the saved conv output.
+constexpr int BNB_THREADS = 240, BNB_BLOCKS = 1024;
+
+struct BnCoef { float mean, rstd, gamma, beta; };
+
+__global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* __restrict__ c, const float* __restrict__ dt,
+                                                           const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ slope,
+                                                           float dscale, size_t npix, double* partial)
+{
+    __shared__ double red[10][3][96];
+    const int tid = threadIdx.x;
+    if (tid < BNB_THREADS) {
+        const int c4 = tid % 24, row = tid / 24;
+        float mean[4], rstd[4], gm[4], bt[4], sl[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ch = c4 * 4 + e;
+            mean[e] = stats[ch];
+            rstd[e] = 1.0f / sqrtf(stats[96 + ch] + 1e-5f);
+            gm[e] = gamma[ch];
+            bt[e] = beta[ch];
+            sl[e] = slope ? slope[ch] : 1.f;
+        }
+        const size_t per = (npix + gridDim.x - 1) / gridDim.x;
+        const size_t p0 = (size_t)blockIdx.x * per, p1 = p0 + per < npix ? p0 + per : npix;
+        float s_dz[4] = {0, 0, 0, 0}, s_dzx[4] = {0, 0, 0, 0}, s_sl[4] = {0, 0, 0, 0};
+        for (size_t p = p0 + row; p < p1; p += 10) {
+            const f32x4 cv = *(const f32x4*)(c + p * 96 + c4 * 4);
+            const f32x4 dv = *(const f32x4*)(dt + p * 96 + c4 * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xh = (cv[e] - mean[e]) * rstd[e];
+                const float z = fmaf(xh, gm[e], bt[e]);
+                const float d = dv[e] * dscale;
+                const bool neg = slope && z < 0.f;
+                const float dz = neg ? d * sl[e] : d;
+                s_dz[e] += dz;
+                s_dzx[e] += dz * xh;
+                if (neg) s_sl[e] += d * z;
+            }
+        }
+        for (int e = 0; e < 4; ++e) {
+            red[row][0][c4 * 4 + e] = (double)s_dz[e];
+            red[row][1][c4 * 4 + e] = (double)s_dzx[e];
+            red[row][2][c4 * 4 + e] = (double)s_sl[e];
+        }
+    }
+    __syncthreads();
+    for (int k = tid; k < 288; k += 256) {
+        const int which = k / 96, ch = k % 96;
+        double a = 0.0;
+        for (int r = 0; r < 10; ++r) a += red[r][which][ch];
+        partial[(size_t)blockIdx.x * 288 + k] = a;
+    }
+}
+
+__global__ __launch_bounds__(288) void bn_bwd_final_kernel(const double* partial, int nb, double npix,
+                                                           const float* stats, const float* gamma, float* coef /*[3][96]*/,
+                                                           float* dgamma, float* dbeta, float* dslope)
+{
+    const int k = threadIdx.x, which = k / 96, ch = k % 96;
+    __shared__ double tot[288];
+    double a = 0.0;
+    for (int b = 0; b < nb; ++b) a += partial[(size_t)b * 288 + k];
+    tot[k] = a;
+    __syncthreads();
+    if (which == 0) {
+        const double rstd = 1.0 / sqrt((double)stats[96 + ch] + 1e-5);
+        const double k1 = (double)gamma[ch] * rstd;
+        coef[ch] = (float)k1;                                   // dc = k1 * dz - k2 - k3 * xhat
+        coef[96 + ch] = (float)(k1 * tot[ch] / npix);
+        coef[192 + ch] = (float)(k1 * tot[96 + ch] / npix);
+        dbeta[ch] = (float)tot[ch];
+        dgamma[ch] = (float)tot[96 + ch];
+        if (dslope) dslope[ch] = (float)tot[192 + ch];
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ c, const float* __restrict__ dt,
+                                                           const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, const float* __restrict__ slope,
+                                                           const float* __restrict__ coef, float dscale, float* __restrict__ dc,
+                                                           size_t n4)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const int ch = (int)(i % 24) * 4;
+        const f32x4 cv = *(const f32x4*)(c + i * 4);
+        const f32x4 dv = *(const f32x4*)(dt + i * 4);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float rstd = 1.0f / sqrtf(stats[96 + ch + e] + 1e-5f);
+            const float xh = (cv[e] - stats[ch + e]) * rstd;
+            const float z = fmaf(xh, gamma[ch + e], beta[ch + e]);
+            const float d = dv[e] * dscale;
+            const float dz = (slope && z < 0.f) ? d * slope[ch + e] : d;
+            o[e] = coef[ch + e] * dz - coef[96 + ch + e] - coef[192 + ch + e] * xh;
+        }
+        *(f32x4*)(dc + i * 4) = o;
+    }
+}
+
+size_t bn_bwd_scratch_bytes() { return (size_t)BNB_BLOCKS * 288 * sizeof(double) + 288 * sizeof(float); }
+
+hipError_t launch_bn_train_bwd(const float* c, const float* dt, const float* stats, const float* gamma, const float* beta,
+                               const float* slope, float dscale, float* dc, float* dgamma, float* dbeta, float* dslope,
+                               size_t npix, void* scratch, hipStream_t s)
+{
+    double* partial = (double*)scratch;
+    float* coef = (float*)(partial + (size_t)BNB_BLOCKS * 288);
+    const int nb = npix < (size_t)BNB_BLOCKS * 10 ? (int)((npix + 9) / 10) : BNB_BLOCKS;
+    hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(nb), dim3(256), 0, s, c, dt, stats, gamma, beta, slope, dscale, npix, partial);
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(1), dim3(288), 0, s, partial, nb, (double)npix, stats, gamma, coef, dgamma,
+                       dbeta, dslope);
+    const size_t n4 = npix * 24;
+    const size_t want = (n4 + 255) / 256;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)(want < 16384 ? want : 16384)), dim3(256), 0, s, c, dt, stats, gamma,
+                       beta, slope, coef, dscale, dc, n4);
+    return hipGetLastError();
+}
+
+// ---- gradient of the pixel losses: weighted_l1(sr, hr) + w_ssim * (1 - ssim(sr, hr)) with respect to sr -------------
+// ssim map S = A1 A2 / (B1 B2) over the five gaussian-filtered maps a = mu_x, b = mu_y, e = E[x^2], f = E[y^2],
+// g = E[xy] (utils.py:26-41; zero-padded 11x11, sigma 1.5; den clamped at 1e-8: no gradient where clamped).
+//   dS/da = (2b (A2 - A1)) / (B1 B2) - A1 A2 (2a (B2 - B1)) / (B1 B2)^2,  dS/de = -A1 A2 / (B1 B2^2),  dS/dg = 2 A1 / (B1 B2)
+//   d ssim / d sr = (1/M) [ G*Da + 2 sr . (G*De) + hr . (G*Dg) ]            (G*: the same zero-padded filter)
+// Kernel 1 (tile kernel, same staging as metrics_tile_kernel) writes the three derivative maps; kernel 2 filters
+// them and adds the weighted-L1 term: (9 [hr > 0.01] + 1) sign(sr - hr) / M  (train.py:18-20).
+constexpr int LT = 32, LH = LT + 10;
+
+__device__ __forceinline__ void gauss11(float* g)
+{
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 11; ++i) { const float d = (float)(i - 5); g[i] = expf(-(d * d) / (2.f * 1.5f * 1.5f)); s += g[i]; }
+#pragma unroll
+    for (int i = 0; i < 11; ++i) g[i] /= s;
+}
+
+__global__ __launch_bounds__(256) void ssim_dmaps_kernel(const float* __restrict__ sr, const float* __restrict__ hr, int h, int w,
+                                                         int tiles_x, int tiles_y, float* __restrict__ dmaps /*[3][planes][h][w]*/,
+                                                         size_t plane_stride_total)
+{
+    __shared__ float a[LH][LH + 1], b[LH][LH + 1];
+    __shared__ float hq[5][LH][LT + 1];
+    float g[11];
+    gauss11(g);
+    int bid = blockIdx.x;
+    const int tx = bid % tiles_x; bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const size_t plane = bid / tiles_y;
+    const float* ps = sr + plane * h * w;
+    const float* ph = hr + plane * h * w;
+    const int x0 = tx * LT - 5, y0 = ty * LT - 5;
+    for (int i = threadIdx.x; i < LH * LH; i += 256) {
+        const int r = i / LH, c = i - r * LH;
+        const int gy = y0 + r, gx = x0 + c;
+        const bool ok = (unsigned)gy < (unsigned)h && (unsigned)gx < (unsigned)w;
+        a[r][c] = ok ? ps[(size_t)gy * w + gx] : 0.f;
+        b[r][c] = ok ? ph[(size_t)gy * w + gx] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < LH * LT; i += 256) {
+        const int r = i / LT, c = i - r * LT;
+        float mx = 0, my = 0, xx = 0, yy = 0, xy = 0;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            const float va = a[r][c + k], vb = b[r][c + k], gk = g[k];
+            mx += gk * va; my += gk * vb; xx += gk * va * va; yy += gk * vb * vb; xy += gk * va * vb;
+        }
+        hq[0][r][c] = mx; hq[1][r][c] = my; hq[2][r][c] = xx; hq[3][r][c] = yy; hq[4][r][c] = xy;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < LT * LT; i += 256) {
+        const int r = i / LT, c = i - r * LT;
+        const int gy = ty * LT + r, gx = tx * LT + c;
+        if (gy < h && gx < w) {
+            float mx = 0, my = 0, xx = 0, yy = 0, xy = 0;
+#pragma unroll
+            for (int k = 0; k < 11; ++k) {
+                const float gk = g[k];
+                mx += gk * hq[0][r + k][c]; my += gk * hq[1][r + k][c]; xx += gk * hq[2][r + k][c];
+                yy += gk * hq[3][r + k][c]; xy += gk * hq[4][r + k][c];
+            }
+            const float c1 = 0.01f * 0.01f, c2 = 0.03f * 0.03f;
+            const float A1 = 2.f * mx * my + c1, A2 = 2.f * (xy - mx * my) + c2;
+            const float B1 = mx * mx + my * my + c1, B2 = (xx - mx * mx) + (yy - my * my) + c2;
+            const float den = B1 * B2;
+            float da = 0.f, de = 0.f, dg = 0.f;
+            if (den >= 1e-8f) {                                   // clamp(min=1e-8): no gradient below it
+                const float inv = 1.f / den;
+                da = 2.f * my * (A2 - A1) * inv - A1 * A2 * (2.f * mx * (B2 - B1)) * inv * inv;
+                de = -A1 * A2 * inv / B2;
+                dg = 2.f * A1 * inv;
+            }
+            const size_t o = plane * h * w + (size_t)gy * w + gx;
+            dmaps[o] = da;
+            dmaps[plane_stride_total + o] = de;
+            dmaps[2 * plane_stride_total + o] = dg;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void pixel_loss_grad_kernel(const float* __restrict__ sr, const float* __restrict__ hr,
+                                                              const float* __restrict__ dmaps, size_t plane_stride_total, int h,
+                                                              int w, int tiles_x, int tiles_y, float w_l1, float w_ssim,
+                                                              float inv_m, float* __restrict__ dsr)
+{
+    __shared__ float d[3][LH][LH + 1];
+    __shared__ float hq[3][LH][LT + 1];
+    float g[11];
+    gauss11(g);
+    int bid = blockIdx.x;
+    const int tx = bid % tiles_x; bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const size_t plane = bid / tiles_y;
+    const int x0 = tx * LT - 5, y0 = ty * LT - 5;
+    for (int i = threadIdx.x; i < LH * LH; i += 256) {
+        const int r = i / LH, c = i - r * LH;
+        const int gy = y0 + r, gx = x0 + c;
+        const bool ok = (unsigned)gy < (unsigned)h && (unsigned)gx < (unsigned)w;
+        const size_t o = plane * h * w + (size_t)gy * w + gx;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) d[k][r][c] = ok ? dmaps[k * plane_stride_total + o] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < LH * LT; i += 256) {
+        const int r = i / LT, c = i - r * LT;
+        float s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) { s0 += g[k] * d[0][r][c + k]; s1 += g[k] * d[1][r][c + k]; s2 += g[k] * d[2][r][c + k]; }
+        hq[0][r][c] = s0; hq[1][r][c] = s1; hq[2][r][c] = s2;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < LT * LT; i += 256) {
+        const int r = i / LT, c = i - r * LT;
+        const int gy = ty * LT + r, gx = tx * LT + c;
+        if (gy < h && gx < w) {
+            float s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+            for (int k = 0; k < 11; ++k) { s0 += g[k] * hq[0][r + k][c]; s1 += g[k] * hq[1][r + k][c]; s2 += g[k] * hq[2][r + k][c]; }
+            const size_t o = plane * h * w + (size_t)gy * w + gx;
+            const float xs = sr[o], ys = hr[o];
+            const float dssim = (s0 + 2.f * xs * s1 + ys * s2) * inv_m;
+            const float df = xs - ys;
+            const float sgn = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
+            const float dl1 = ((ys > 0.01f ? 1.f : 0.f) * 9.f + 1.f) * sgn * inv_m;
+            dsr[o] = w_l1 * dl1 - w_ssim * dssim;
+        }
+    }
+}
+
+hipError_t launch_pixel_loss_grad(const float* sr, const float* hr, int n, int c, int h, int w, float w_l1, float w_ssim,
+                                  float* dsr, void* scratch, hipStream_t s)
+{
+    const int tiles_x = (w + LT - 1) / LT, tiles_y = (h + LT - 1) / LT;
+    const int nb = n * c * tiles_x * tiles_y;
+    const size_t total = (size_t)n * c * h * w;
+    float* dmaps = (float*)scratch;
+    hipLaunchKernelGGL(ssim_dmaps_kernel, dim3((unsigned)nb), dim3(256), 0, s, sr, hr, h, w, tiles_x, tiles_y, dmaps, total);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(pixel_loss_grad_kernel, dim3((unsigned)nb), dim3(256), 0, s, sr, hr, dmaps, total, h, w, tiles_x, tiles_y,
+                       w_l1, w_ssim, 1.0f / (float)total, dsr);
+    return hipGetLastError();
+}
+
+// ---- AdamW (torch.optim.AdamW: decoupled weight decay, bias-corrected moments) over a flat buffer ----------------
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, size_t n, float lr, float beta1, float beta2, float eps,
+                                                    float wd, float bc1, float bc2_sqrt)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float gi = g[i];
+        float pi = p[i] * (1.f - lr * wd);                       // param.mul_(1 - lr * weight_decay)
+        const float mi = beta1 * m[i] + (1.f - beta1) * gi;      // exp_avg.lerp_(grad, 1 - beta1)
+        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        pi -= (lr / bc1) * (mi / denom);
+        p[i] = pi;
+    }
+}
+
+hipError_t launch_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
+                        float wd, int step, hipStream_t s)
+{
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, n, lr, beta1, beta2, eps, wd, (float)bc1,
+                       (float)sqrt(bc2));
+    return hipGetLastError();
+}
+
+}  // namespace srgen

@@ -1,0 +1,174 @@
+"""GPU: pre-train step operators (train.py:90-97,270) on the HIP path against
+(a) tests/golden/train_ops.npz -- the REAL reference's modules run backward with autograd (make_golden_bwd.py) and
+(b) torch autograd of the same stock ops on the box's CPU for other shapes / seeds.
+Tolerance: gradients <= 1e-4 of max|reference gradient| (the fp32 bar of BASELINE.json's north_star, applied per tensor)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import GOLDEN, max_rel
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(GOLDEN, "train_ops.npz"))
+
+
+def _hash_tensor(seed, key, shape, lo=-1.0, hi=1.0):
+    from superresolution_amd import weights as W
+    n = int(np.prod(shape))
+    return torch.from_numpy((lo + (hi - lo) * W.hash_uniform(seed, key, n)).astype(np.float32).reshape(shape))
+
+
+def _nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def _nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+def _resblock(seed=0):
+    from superresolution_amd import weights as W
+    from superresolution_amd.generator import ResBlock
+    sd = W.synthetic_state_dict(seed)
+    rb = ResBlock(96)
+    rb.load_state_dict({k[len("blocks.0."):]: v for k, v in sd.items() if k.startswith("blocks.0.")})
+    return rb
+
+
+def test_resblock_backward_vs_reference_golden(gold):
+    """Generator.ResBlock in train mode, forward + backward, against the real reference's autograd."""
+    from superresolution_amd import training as T
+    rb = _resblock().cuda()
+    ws = T.Workspace(torch.device("cuda"))
+    x = _nhwc(_hash_tensor(11, "bwd.x", (3, 96, 64, 64))).cuda()
+    gr = _nhwc(_hash_tensor(12, "bwd.g", (3, 96, 64, 64))).cuda()
+    out, saved = T.resblock_forward(x, rb, ws)
+    assert max_rel(_nchw(out).cpu().flatten()[::257].numpy(), gold["resblock_out_sample"]) <= TOL
+    for i, st in ((1, saved["st1"]), (4, saved["st2"])):
+        assert np.abs(st[0].cpu().numpy() - gold[f"resblock_bn{i}_mean"]).max() <= 1e-5
+        assert max_rel(st[1].cpu().numpy(), gold[f"resblock_bn{i}_var_biased"]) <= 1e-4
+    dx, grads = T.resblock_backward(gr, saved, rb, ws)
+    dxc = _nchw(dx).cpu()
+    err = max_rel(dxc.flatten()[::257].numpy(), gold["resblock_dx_sample"])
+    print("resblock dx err", err)
+    assert err <= TOL
+    s = np.array([dxc.double().sum().item(), (dxc.double() ** 2).sum().item()])
+    assert abs(s[1] - gold["resblock_dx_sums"][1]) <= 1e-4 * gold["resblock_dx_sums"][1]
+    for k, g in grads.items():
+        gc = g.cpu()
+        if gc.dim() == 4:
+            ref, ref_s = gold[f"resblock_grad_{k}_sample"], gold[f"resblock_grad_{k}_sums"]
+            e = max_rel(gc.flatten()[::5].numpy(), ref)
+            assert abs((gc.double() ** 2).sum().item() - ref_s[1]) <= 1e-4 * ref_s[1], k
+        else:
+            ref = gold[f"resblock_grad_{k}"]
+            # a conv bias in front of a train-mode BatchNorm has gradient sum(dc) = 0 exactly: what both sides hold
+            # is the rounding residue of a cancellation whose terms are of the size of dbeta -> scale by that
+            scale = max(np.abs(ref).max(), float(np.abs(gold["resblock_grad_block.4.bias"]).max()))
+            e = float(np.abs(gc.numpy() - ref).max() / scale)
+        print("resblock grad", k, e)
+        assert e <= TOL, k
+
+
+def test_resblock_backward_vs_torch_autograd_other_seed():
+    """Another weight seed, batch 1 and a ragged batch, against torch autograd of the stock ops (CPU).
+    (PReLU's derivative jumps at 0: a pre-activation within rounding of 0 may fall on different sides in two correct
+    fp32 computations and flips one gradient element by O(1) -- the (n, seed) pairs here have no such element; n = 5
+    with seed 4 has exactly one.)"""
+    from superresolution_amd import training as T
+    for n, seed in ((1, 3), (6, 4)):
+        rb = _resblock(seed)
+        x = _hash_tensor(20 + n, "x", (n, 96, 64, 64))
+        gr = _hash_tensor(30 + n, "g", (n, 96, 64, 64))
+        xr = x.clone().requires_grad_(True)
+        seq = rb.block
+        t = F.conv2d(xr, seq[0].weight, seq[0].bias, padding=1)
+        t = F.prelu(F.batch_norm(t, None, None, seq[1].weight, seq[1].bias, training=True, eps=1e-5), seq[2].weight)
+        t = F.batch_norm(F.conv2d(t, seq[3].weight, seq[3].bias, padding=1), None, None, seq[4].weight, seq[4].bias,
+                         training=True, eps=1e-5)
+        ((xr + 0.1 * t) * gr).sum().backward()
+        ref = {k: p.grad.clone() for k, p in rb.named_parameters()}
+        rbc = _resblock(seed).cuda()
+        ws = T.Workspace(torch.device("cuda"))
+        out, saved = T.resblock_forward(_nhwc(x).cuda(), rbc, ws)
+        dx, grads = T.resblock_backward(_nhwc(gr).cuda(), saved, rbc, ws)
+        assert max_rel(_nchw(dx).cpu().numpy(), xr.grad.numpy()) <= TOL, n
+        big = max(float(v.abs().max()) for v in ref.values())
+        for k, g in grads.items():
+            scale = big if k.endswith((".0.bias", ".3.bias")) else float(ref[k].abs().max())   # (see the golden test)
+            assert float((g.cpu() - ref[k]).abs().max()) / scale <= TOL, (n, k)
+
+
+def test_conv3x3_dgrad_and_wgrad_at_128(gold):
+    """output[0] of the generator runs at 128 x 128 (Generator.py:69): the same operators at that size."""
+    from superresolution_amd import training as T
+    torch.manual_seed(5)
+    w = (torch.rand(96, 96, 3, 3) - 0.5) * 0.1
+    b = (torch.rand(96) - 0.5) * 0.1
+    x = _hash_tensor(41, "x", (2, 96, 128, 128))
+    gr = _hash_tensor(42, "g", (2, 96, 128, 128))
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    (F.conv2d(xr, wr, br, padding=1) * gr).sum().backward()
+    ws = T.Workspace(torch.device("cuda"))
+    wc = w.cuda()
+    y = T.conv3x3(_nhwc(x).cuda(), T.wino_pack(wc), b.cuda())
+    assert max_rel(_nchw(y).cpu().numpy(), F.conv2d(x, w, b, padding=1).numpy()) <= TOL
+    dx = T.conv3x3(_nhwc(gr).cuda(), T.wino_pack(wc, mode=1))
+    assert max_rel(_nchw(dx).cpu().numpy(), xr.grad.numpy()) <= TOL
+    dw, db = T.conv3x3_wgrad(_nhwc(x).cuda(), _nhwc(gr).cuda(), ws)
+    assert max_rel(dw.cpu().numpy(), wr.grad.numpy()) <= TOL
+    assert max_rel(db.cpu().numpy(), br.grad.numpy()) <= TOL
+
+
+def test_pixel_loss_grad_vs_reference_golden(gold, golden):
+    from superresolution_amd import pixel_losses, training as T, weights as W
+    ws = T.Workspace(torch.device("cuda"))
+    sr = torch.from_numpy(golden["y_dense_sparse"]).cuda()
+    hr = torch.from_numpy(W.synthetic_hr_batch(2, seed=1)).cuda()
+    vals = pixel_losses(sr, hr).cpu().numpy()                      # [psnr, ssim, l1, weighted_l1]
+    for tag, w_l1, w_ssim in (("pre", 1.0, 0.1), ("gan", 1.0, 0.3)):
+        assert abs(w_l1 * vals[3] + w_ssim * (1 - vals[1]) - float(gold[f"loss_{tag}_value"])) <= 1e-5
+        d = T.pixel_loss_grad(sr, hr, ws, w_l1, w_ssim).cpu()
+        e = max_rel(d.flatten()[::3].numpy(), gold[f"loss_{tag}_dsr_sample"])
+        print("loss grad", tag, e)
+        assert e <= TOL
+        ref_s = gold[f"loss_{tag}_dsr_sums"]
+        assert abs((d.double() ** 2).sum().item() - ref_s[1]) <= 1e-4 * ref_s[1]
+
+
+def test_pixel_loss_grad_ragged_shape_vs_torch_autograd():
+    from oracle import torch_ref as TR
+    from superresolution_amd import training as T
+    ws = T.Workspace(torch.device("cuda"))
+    rng = np.random.default_rng(6)
+    sr = torch.from_numpy(rng.random((3, 2, 37, 70), dtype=np.float32))
+    hr = torch.from_numpy((rng.random((3, 2, 37, 70), dtype=np.float32) * 0.03))         # straddles the 0.01 weight step
+    srr = sr.clone().requires_grad_(True)
+    w = (hr > 0.01).float() * 9 + 1
+    (0.7 * (w * (srr - hr).abs()).mean() + 0.3 * (1 - TR.ssim(srr, hr))).backward()
+    d = T.pixel_loss_grad(sr.cuda(), hr.cuda(), ws, 0.7, 0.3).cpu()
+    assert max_rel(d.numpy(), srr.grad.numpy()) <= TOL
+
+
+def test_flat_adamw_vs_reference_golden(gold):
+    from superresolution_amd import training as T
+    p = torch.nn.Parameter(_hash_tensor(13, "adamw.p", (4099,)).cuda())
+    q = torch.nn.Parameter(torch.zeros(7, 3).cuda())               # a second tensor in the same flat buffer
+    opt = T.FlatAdamW([p, q], lr=1e-4)
+    assert p.data_ptr() == opt.flat.data_ptr() and p.grad.data_ptr() == opt.flat_grad.data_ptr()
+    for step in range(1, 4):
+        opt.zero_grad()
+        p.grad.copy_(_hash_tensor(13 + step, "adamw.g", (4099,), -0.05, 0.05).cuda())
+        opt.step()
+        err = float(np.abs(p.detach().cpu().numpy() - gold[f"adamw_p{step}"]).max())
+        print("adamw step", step, err)
+        assert err <= 2e-7
+    assert torch.equal(q.detach().cpu(), torch.zeros(7, 3))        # zero gradient, zero value: stays zero
