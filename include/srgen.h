@@ -178,9 +178,8 @@ SRGEN_API int srgen_pixel_losses(const float* sr, const float* hr, int n, int c,
 /* ---- Pre-train step operators (backward pass + optimizer) -------------------------------------------------
  * SURVEY.md 8(f) "next" row 2: what autograd and torch.optim.AdamW do for the reference's pre-train step
  * (train.py:90-97: loss.backward(), optimizer.step(); train.py:270: AdamW(lr 1e-4, default weight decay 0.01)),
- * as operators on fp32 NHWC activations (n, hw, hw, 96).  First slice: everything the residual trunk
- * (Generator.py:30-42: conv3x3 -> BatchNorm -> PReLU -> conv3x3 -> BatchNorm, x + 0.1 * block) and the pixel losses
- * need; superresolution_amd/training.py composes them.  All pointers are device pointers; nothing synchronises. */
+ * as operators on fp32 NHWC activations (n, hw, hw, 96), one per layer type of the generator (Generator.py:45-80);
+ * superresolution_amd/training.py composes them into forward + backward + optimizer step.  All pointers are device pointers; nothing synchronises. */
 
 /* Replaces: the weight side of F.conv2d(x, w, padding=1) and of its data gradient.  Forms the Winograd weight image
  * the 3x3 kernel reads (U = G g Gt, fp64 on the device, rounded once) from OIHW fp32 weights that change every step.
@@ -216,6 +215,48 @@ SRGEN_API int srgen_bn_train_bwd(const float* c, const float* dout, const float*
                                  const float* beta, const float* slope, float dout_scale, float* dc, float* dgamma,
                                  float* dbeta, float* dslope, size_t npix, void* scratch, size_t scratch_bytes,
                                  void* stream);
+
+/* Replaces: nn.PReLU() with ONE slope (Generator.py:51, 9, 70) forward and backward, elementwise over numel floats
+ * (a multiple of 4).  slope / dslope: one device float.  y may alias x; dx may alias dy.  dy2 (may be NULL): a second
+ * gradient added to dy first -- the PReLU output has two consumers where the long skip branches off (Generator.py:75,78). */
+SRGEN_API int srgen_prelu_scratch_bytes(size_t* bytes);
+SRGEN_API int srgen_prelu_scalar_fwd(const float* x, const float* slope, float* y, size_t numel, void* stream);
+SRGEN_API int srgen_prelu_scalar_bwd(const float* x, const float* dy, const float* dy2, const float* slope, float* dx,
+                                     float* dslope, size_t numel, void* scratch, size_t scratch_bytes, void* stream);
+
+/* Replaces: the 9x9 convs between a 3-channel NCHW image and a 96-channel NHWC tensor, in the four forms the step needs
+ * (Generator.py:50 input[0], :71 output[2]).  j = (c3, ky, kx) runs over 243 taps; a tap of pixel (y, x) reads
+ * img[n][c3][y + s (ky - 4)][x + s (kx - 4)], s = +1 (flip 0) / -1 (flip 1), zero outside the ih x iw image.
+ *   srgen_conv9x9_c3_nhwc : out[n][y][x][c] = bias[c] + sum_j tap_j * wm[j][c]      (wm: [243][96]; bias may be NULL)
+ *       flip 0: stem forward, F.conv2d(lr, w, b, padding=4) with wm[(ci,ky,kx)][co] = w[co][ci][ky][kx];
+ *       flip 1: data gradient of the head conv: img = d out (n, 3, 125, 125), out = (n, 128, 128, 96),
+ *               wm[(co,ky,kx)][ci] = w[co][ci][ky][kx]
+ *   srgen_conv9x9_c3_wgrad: r[c][j] = sum over pixels act[n][y][x][c] * tap_j        (r: [96][243])
+ *       flip 0: weight gradient of the stem (act = d x1, img = lr): r = dw (96, 3, 9, 9); dbias [96] = sum act
+ *       flip 1: weight gradient of the head (act = the head's input, img = d out): r[ci][(co,ky,kx)] = dw[co][ci][ky][kx] */
+SRGEN_API int srgen_conv9x9_c3_nhwc(const float* img, const float* wm, const float* bias, float* out, int n, int ih,
+                                    int iw, int oh, int ow, int flip, void* stream);
+SRGEN_API int srgen_conv9x9_c3_wgrad_scratch_bytes(int n, int ah, size_t* bytes);
+SRGEN_API int srgen_conv9x9_c3_wgrad(const float* act, const float* img, int n, int ah, int aw, int ih, int iw, int flip,
+                                     float* r, float* dbias, void* scratch, size_t scratch_bytes, void* stream);
+
+/* Replaces: F.conv2d(v, w, b, padding=4)[:, :, :125, :125] of Generator.py:71,80 on an NHWC (n, 128, 128, 96) input with
+ * weights that change every step: wpack = the head kernel's weight image, float2 units [ky 9][c8 12][u 2][h 2][n 32] with
+ * ci = 8 c8 + 2 (2u + h) + e, n = 3 kx + co (27 used) -- superresolution_amd/training.py forms it on the device.
+ * y: (n, 3, 125, 125) NCHW. */
+SRGEN_API int srgen_head_nhwc(const float* v, const float* wpack, const float* bias, float* y, int n, void* stream);
+
+/* Replaces: ChannelAttention.forward and its backward (Generator.py:15-27) on an NHWC (n, 64, 64, 96) tensor.
+ *   fwd: x is scaled IN PLACE by s = sigmoid(W2 relu(W1 mean_hw(x) + b1) + b2); pool_partial [n][16][96] (channel sums of
+ *        16 row bands) and scale [n][96] are returned for the backward
+ *   bwd: x = the UNSCALED input; dx = dy * s + dpool / 4096; dw1 (12, 96), db1 (12), dw2 (96, 12), db2 (96) summed over the
+ *        batch in image order */
+SRGEN_API int srgen_chan_attn_nhwc(float* x, const float* w1, const float* b1, const float* w2, const float* b2,
+                                   float* pool_partial, float* scale, int n, void* stream);
+SRGEN_API int srgen_chan_attn_bwd_scratch_bytes(int n, size_t* bytes);
+SRGEN_API int srgen_chan_attn_bwd(const float* x, const float* dy, const float* pool_partial, const float* scale, int n,
+                                  const float* w1, const float* b1, const float* w2, const float* b2, float* dx, float* dw1,
+                                  float* db1, float* dw2, float* db2, void* scratch, size_t scratch_bytes, void* stream);
 
 /* Replaces: autograd through the pre-train loss (train.py:93): dsr = d/dsr [w_l1 * weighted_l1(sr, hr) +
  * w_ssim * (1 - ssim(sr, hr))] (train.py:18-20; utils.py:21-41), sr / hr / dsr (n, c, hgt, wid) NCHW fp32.

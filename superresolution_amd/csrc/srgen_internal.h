@@ -172,6 +172,20 @@ hipError_t launch_bn_train_bwd(const float* c, const float* dt, const float* sta
 // dsr = d/dsr [w_l1 * weighted_l1(sr, hr) + w_ssim * (1 - ssim(sr, hr))]; scratch: 3 * n*c*h*w floats
 hipError_t launch_pixel_loss_grad(const float* sr, const float* hr, int n, int c, int h, int w, float w_l1, float w_ssim,
                                   float* dsr, void* scratch, hipStream_t s);
+size_t prelu_scratch_bytes();
+hipError_t launch_prelu_scalar_fwd(const float* x, const float* slope, float* y, size_t numel, hipStream_t s);
+hipError_t launch_prelu_scalar_bwd(const float* x, const float* dy, const float* dy2, const float* slope, float* dx, float* dslope,
+                                   size_t numel, void* scratch, hipStream_t s);
+// 9x9 convs against a 3-channel NCHW image (see srgen_train_kernels.hip): wm [243][96]; r [96][243]
+hipError_t launch_conv9x9_c3(const float* img, const float* wm, const float* bias, float* out, int n, int ih, int iw, int oh,
+                             int ow, int flip, hipStream_t s);
+size_t conv9x9_c3_wgrad_scratch_bytes(int n, int ah);
+hipError_t launch_conv9x9_c3_wgrad(const float* act, const float* img, int n, int ah, int aw, int ih, int iw, int flip, float* r,
+                                   float* dbias, void* scratch, hipStream_t s);
+size_t chan_attn_bwd_scratch_bytes(int n);
+hipError_t launch_chan_attn_bwd(const float* x, const float* dy, const float* pool_partial, const float* scale, int n, int hw,
+                                const float* w1, const float* b1, const float* w2, const float* b2, float* dx, float* dw1, float* db1,
+                                float* dw2, float* db2, void* scratch, hipStream_t s);
 hipError_t launch_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
                         float wd, int step, hipStream_t s);
 hipError_t launch_pool_partial(const float* t, int n, int hw, int parts, float* pool_partial, hipStream_t s);

@@ -163,4 +163,100 @@ int srgen_adamw(float* p, const float* g, float* m, float* v, size_t numel, floa
     return SRGEN_OK;
 }
 
+
+int srgen_prelu_scratch_bytes(size_t* bytes)
+{
+    if (!bytes) return fail(SRGEN_E_INVALID, "bytes is NULL");
+    *bytes = (prelu_scratch_bytes() + 255) & ~(size_t)255;
+    return SRGEN_OK;
+}
+
+int srgen_prelu_scalar_fwd(const float* x, const float* slope, float* y, size_t numel, void* stream)
+{
+    if (numel == 0) return SRGEN_OK;
+    if (!x || !slope || !y) return fail(SRGEN_E_INVALID, "NULL argument");
+    if ((numel & 3) || !aligned16(x) || !aligned16(y)) return fail(SRGEN_E_INVALID, "numel must be a multiple of 4, operands 16-byte aligned");
+    HIP_TRY(launch_prelu_scalar_fwd(x, slope, y, numel, (hipStream_t)stream));
+    return SRGEN_OK;
+}
+
+int srgen_prelu_scalar_bwd(const float* x, const float* dy, const float* dy2, const float* slope, float* dx, float* dslope,
+                           size_t numel, void* scratch, size_t scratch_bytes, void* stream)
+{
+    if (!x || !dy || !slope || !dx || !dslope || !scratch) return fail(SRGEN_E_INVALID, "NULL argument");
+    if (numel == 0 || (numel & 3) || !aligned16(x) || !aligned16(dy) || !aligned16(dy2) || !aligned16(dx))
+        return fail(SRGEN_E_INVALID, "numel must be a positive multiple of 4, operands 16-byte aligned");
+    if (scratch_bytes < prelu_scratch_bytes()) return fail(SRGEN_E_WORKSPACE, "PReLU scratch too small");
+    HIP_TRY(launch_prelu_scalar_bwd(x, dy, dy2, slope, dx, dslope, numel, scratch, (hipStream_t)stream));
+    return SRGEN_OK;
+}
+
+int srgen_conv9x9_c3_nhwc(const float* img, const float* wm, const float* bias, float* out, int n, int ih, int iw, int oh, int ow,
+                          int flip, void* stream)
+{
+    if (!img || !wm || !out) return fail(SRGEN_E_INVALID, "NULL argument");
+    if (n <= 0 || ih <= 0 || iw <= 0 || oh <= 0 || ow <= 0) return fail(SRGEN_E_INVALID, "bad shape");
+    if ((ow & 15) || (((long long)n * oh * ow) & 63)) return fail(SRGEN_E_UNSUPPORTED, "output width must be a multiple of 16 and n*oh*ow of 64");
+    if (!aligned16(out) || !aligned16(bias)) return fail(SRGEN_E_INVALID, "out / bias must be 16-byte aligned");
+    HIP_TRY(launch_conv9x9_c3(img, wm, bias, out, n, ih, iw, oh, ow, flip ? 1 : 0, (hipStream_t)stream));
+    return SRGEN_OK;
+}
+
+int srgen_conv9x9_c3_wgrad_scratch_bytes(int n, int ah, size_t* bytes)
+{
+    if (!bytes || n <= 0 || ah <= 0) return fail(SRGEN_E_INVALID, "bad argument");
+    *bytes = (conv9x9_c3_wgrad_scratch_bytes(n, ah) + 255) & ~(size_t)255;
+    return SRGEN_OK;
+}
+
+int srgen_conv9x9_c3_wgrad(const float* act, const float* img, int n, int ah, int aw, int ih, int iw, int flip, float* r,
+                           float* dbias, void* scratch, size_t scratch_bytes, void* stream)
+{
+    if (!act || !img || !r || !scratch) return fail(SRGEN_E_INVALID, "NULL argument");
+    if (n <= 0 || ah <= 0 || aw <= 0 || (aw & 3) || ih <= 0 || iw <= 0) return fail(SRGEN_E_INVALID, "bad shape");
+    if (scratch_bytes < conv9x9_c3_wgrad_scratch_bytes(n, ah)) return fail(SRGEN_E_WORKSPACE, "9x9 wgrad scratch too small");
+    HIP_TRY(launch_conv9x9_c3_wgrad(act, img, n, ah, aw, ih, iw, flip ? 1 : 0, r, dbias, scratch, (hipStream_t)stream));
+    return SRGEN_OK;
+}
+
+int srgen_head_nhwc(const float* v, const float* wpack, const float* bias, float* y, int n, void* stream)
+{
+    if (!v || !wpack || !bias || !y) return fail(SRGEN_E_INVALID, "NULL argument");
+    if (n <= 0) return fail(SRGEN_E_INVALID, "batch %d", n);
+    HeadArgs a{v, y, wpack, bias, n};
+    HIP_TRY(launch_head_f32(a, (hipStream_t)stream));
+    return SRGEN_OK;
+}
+
+int srgen_chan_attn_nhwc(float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* pool_partial,
+                         float* scale, int n, void* stream)
+{
+    if (!x || !w1 || !b1 || !w2 || !b2 || !pool_partial || !scale) return fail(SRGEN_E_INVALID, "NULL argument");
+    if (n <= 0) return fail(SRGEN_E_INVALID, "batch %d", n);
+    HIP_TRY(launch_pool_partial(x, n, kLR * kLR, 16, pool_partial, (hipStream_t)stream));
+    ChanAttnArgs a{x, pool_partial, 16, w1, b1, w2, b2, scale, n, kLR * kLR};
+    HIP_TRY(launch_chan_attn_f32(a, (hipStream_t)stream));
+    return SRGEN_OK;
+}
+
+int srgen_chan_attn_bwd_scratch_bytes(int n, size_t* bytes)
+{
+    if (!bytes || n <= 0) return fail(SRGEN_E_INVALID, "bad argument");
+    *bytes = (chan_attn_bwd_scratch_bytes(n) + 255) & ~(size_t)255;
+    return SRGEN_OK;
+}
+
+int srgen_chan_attn_bwd(const float* x, const float* dy, const float* pool_partial, const float* scale, int n, const float* w1,
+                        const float* b1, const float* w2, const float* b2, float* dx, float* dw1, float* db1, float* dw2,
+                        float* db2, void* scratch, size_t scratch_bytes, void* stream)
+{
+    if (!x || !dy || !pool_partial || !scale || !w1 || !b1 || !w2 || !b2 || !dx || !dw1 || !db1 || !dw2 || !db2 || !scratch)
+        return fail(SRGEN_E_INVALID, "NULL argument");
+    if (n <= 0) return fail(SRGEN_E_INVALID, "batch %d", n);
+    if (scratch_bytes < chan_attn_bwd_scratch_bytes(n)) return fail(SRGEN_E_WORKSPACE, "attention scratch too small");
+    HIP_TRY(launch_chan_attn_bwd(x, dy, pool_partial, scale, n, kLR * kLR, w1, b1, w2, b2, dx, dw1, db1, dw2, db2, scratch,
+                                 (hipStream_t)stream));
+    return SRGEN_OK;
+}
+
 }  // extern "C"

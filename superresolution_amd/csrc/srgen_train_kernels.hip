@@ -479,4 +479,408 @@ hipError_t launch_adamw(float* p, const float* g, float* m, float* v, size_t n, 
     return hipGetLastError();
 }
 
+
+// ---- scalar-slope PReLU (Generator.py:51, 9, 70), elementwise over any fp32 tensor -----------------------------------
+__global__ __launch_bounds__(256) void prelu_scalar_fwd_kernel(const float* __restrict__ x, const float* __restrict__ slope,
+                                                               float* __restrict__ y, size_t n4)
+{
+    const float a = slope[0];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        f32x4 v = *(const f32x4*)(x + i * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.f ? v[e] : v[e] * a;
+        *(f32x4*)(y + i * 4) = v;
+    }
+}
+
+// dx = dy * (x >= 0 ? 1 : a), dy = dy1 (+ dy2: a second consumer of the PReLU output, e.g. the long skip);
+// per-workgroup partial of da = sum dy * x * [x < 0] (fp64 across threads)
+__global__ __launch_bounds__(256) void prelu_scalar_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                               const float* __restrict__ dy2, const float* __restrict__ slope,
+                                                               float* __restrict__ dx, size_t n4, double* __restrict__ partial)
+{
+    __shared__ double red[256];
+    const float a = slope[0];
+    float acc = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const f32x4 v = *(const f32x4*)(x + i * 4);
+        f32x4 d = *(const f32x4*)(dy + i * 4);
+        if (dy2) d += *(const f32x4*)(dy2 + i * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (v[e] < 0.f) { acc += d[e] * v[e]; d[e] *= a; }
+        *(f32x4*)(dx + i * 4) = d;
+    }
+    red[threadIdx.x] = (double)acc;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restrict__ partial, int nb, float* __restrict__ out)
+{
+    __shared__ double red[256];
+    double a = 0.0;
+    for (int i = threadIdx.x; i < nb; i += 256) a += partial[i];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (float)red[0];
+}
+
+constexpr int PRELU_BLOCKS = 2048;
+size_t prelu_scratch_bytes() { return PRELU_BLOCKS * sizeof(double); }
+
+hipError_t launch_prelu_scalar_fwd(const float* x, const float* slope, float* y, size_t numel, hipStream_t s)
+{
+    const size_t n4 = numel / 4;
+    size_t nb = (n4 + 255) / 256;
+    if (nb > 16384) nb = 16384;
+    hipLaunchKernelGGL(prelu_scalar_fwd_kernel, dim3((unsigned)nb), dim3(256), 0, s, x, slope, y, n4);
+    return hipGetLastError();
+}
+
+hipError_t launch_prelu_scalar_bwd(const float* x, const float* dy, const float* dy2, const float* slope, float* dx, float* dslope,
+                                   size_t numel, void* scratch, hipStream_t s)
+{
+    const size_t n4 = numel / 4;
+    size_t nb = (n4 + 255) / 256;
+    if (nb > PRELU_BLOCKS) nb = PRELU_BLOCKS;
+    hipLaunchKernelGGL(prelu_scalar_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, s, x, dy, dy2, slope, dx, n4, (double*)scratch);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, (const double*)scratch, (int)nb, dslope);
+    return hipGetLastError();
+}
+
+// ---- 9x9 convs against a 3-channel NCHW image (stem Generator.py:50; head Generator.py:71 transposed) -------------------
+// One GEMM shape serves four uses: K or N = j = (c3, ky, kx), 243 taps (padded to 244 / 256), the other side = 96 channels.
+//   tap of output / activation pixel (y, x):  img[n][c3][y + s*(ky-4)][x + s*(kx-4)],  s = +1 (flip = 0) or -1 (flip = 1),
+//   zero outside the ih x iw image.
+//   conv9x9_c3_kernel   : out[n][y][x][c] = bias[c] + sum_j tap_j * wm[j][c]
+//        flip 0: the stem forward (img = lr input, wm[j][co] = w[co][ci][ky][kx]);
+//        flip 1: the head's data gradient (img = d out, 125 x 125, wm[(co,ky,kx)][ci] = w[co][ci][ky][kx], out 128 x 128).
+//   conv9x9_c3_wgrad    : r[c][j] = sum over pixels act[n][y][x][c] * tap_j
+//        flip 0: the stem's weight gradient (act = d x1, img = lr input): r = dw[co][ci][ky][kx];
+//        flip 1: the head's weight gradient (act = head input, img = d out): r[ci][(co,ky,kx)] = dw[co][ci][ky][kx].
+// Both on v_mfma_f32_16x16x4_f32 with operands straight from memory (the image is tiny and cache resident).
+__device__ __forceinline__ void tap_split(int j, int& c3, int& ky, int& kx)
+{
+    c3 = j / 81;
+    const int r = j - c3 * 81;
+    ky = r / 9;
+    kx = r - ky * 9;
+}
+
+__global__ __launch_bounds__(256) void conv9x9_c3_kernel(const float* __restrict__ img, const float* __restrict__ wm,
+                                                         const float* __restrict__ bias, float* __restrict__ out, int ih, int iw,
+                                                         int oh, int ow, int flip, long long total_pix)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int col = lane & 15, kq = lane >> 4;
+    const long long p0 = ((long long)blockIdx.x * 4 + wv) * 64;          // this wave's 64 consecutive output pixels
+    if (p0 >= total_pix) return;
+    // per pixel tile t: pixel p0 + 16 t + col (a row never straddles a tile: ow is a multiple of 16)
+    int py[4], px[4];
+    const float* ib[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const long long p = p0 + 16 * t + col;
+        const long long n = p / ((long long)oh * ow);
+        const int rem = (int)(p - n * (long long)oh * ow);
+        py[t] = rem / ow;
+        px[t] = rem - py[t] * ow;
+        ib[t] = img + (size_t)n * 3 * ih * iw;
+    }
+    f32x4 acc[6][4];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+        if (bias) b4 = *(const f32x4*)(bias + 16 * a + 4 * kq);          // D rows 4*kq + r = channels 16a + 4kq + r
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[a][t] = b4;
+    }
+    const int sg = flip ? -1 : 1;
+    for (int s = 0; s < 61; ++s) {
+        const int j = 4 * s + kq;
+        int c3, ky, kx;
+        tap_split(j, c3, ky, kx);
+        const bool jv = j < 243;
+        float av[6], bv[4];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) av[a] = jv ? wm[(size_t)j * 96 + 16 * a + col] : 0.f;      // A[i = channel][k = tap]
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int yy = py[t] + sg * (ky - 4), xx = px[t] + sg * (kx - 4);
+            const bool ok = jv && (unsigned)yy < (unsigned)ih && (unsigned)xx < (unsigned)iw;
+            bv[t] = ok ? ib[t][((size_t)c3 * ih + yy) * iw + xx] : 0.f;                         // B[k = tap][j = pixel]
+        }
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[t], acc[a][t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        float* o = out + (size_t)(p0 + 16 * t + col) * 96 + 4 * kq;       // D[row = channel 4kq + r][col = pixel]
+#pragma unroll
+        for (int a = 0; a < 6; ++a) *(f32x4*)(o + 16 * a) = acc[a][t];
+    }
+}
+
+hipError_t launch_conv9x9_c3(const float* img, const float* wm, const float* bias, float* out, int n, int ih, int iw, int oh,
+                             int ow, int flip, hipStream_t s)
+{
+    const long long total = (long long)n * oh * ow;
+    hipLaunchKernelGGL(conv9x9_c3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, img, wm, bias, out, ih, iw, oh,
+                       ow, flip, total);
+    return hipGetLastError();
+}
+
+// slab [slice][96][256]; wave wv owns taps j in [64 wv, 64 wv + 64) x all 96 channels
+__global__ __launch_bounds__(256) void conv9x9_c3_wgrad_kernel(const float* __restrict__ act, const float* __restrict__ img,
+                                                               int total_rows, int ah, int aw, int ih, int iw, int flip,
+                                                               int rows_per_slice, float* __restrict__ slab,
+                                                               float* __restrict__ bias_slab)
+{
+    const int slice = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int col = lane & 15, kq = lane >> 4;
+    const int sg = flip ? -1 : 1;
+    int toff[4], tdy[4], tdx[4];
+    bool tv[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int j = 64 * wv + 16 * t + col;
+        int c3, ky, kx;
+        tap_split(j, c3, ky, kx);
+        tv[t] = j < 243;
+        tdy[t] = sg * (ky - 4);
+        tdx[t] = sg * (kx - 4);
+        toff[t] = (c3 * ih + tdy[t]) * iw + tdx[t];
+    }
+    f32x4 acc[6][4];
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[a][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int r0 = slice * rows_per_slice, r1 = min(r0 + rows_per_slice, total_rows);
+    for (int row = r0; row < r1; ++row) {
+        const int n = row / ah, y = row - n * ah;
+        const float* ar = act + (size_t)row * aw * 96 + col;
+        const float* ibase = img + (size_t)n * 3 * ih * iw + (size_t)y * iw;
+        for (int x0 = 0; x0 < aw; x0 += 4) {
+            const int x = x0 + kq;
+            float av[6], bv[4];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) av[a] = ar[(size_t)x * 96 + 16 * a];                    // A[i = channel][k = pixel]
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const bool ok = tv[t] && (unsigned)(y + tdy[t]) < (unsigned)ih && (unsigned)(x + tdx[t]) < (unsigned)iw;
+                bv[t] = ok ? ibase[toff[t] + x] : 0.f;                                           // B[k = pixel][j = tap]
+            }
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                if (wv == 0) bsum[a] += av[a];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[a][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[t], acc[a][t], 0, 0, 0);
+            }
+        }
+    }
+    float* o = slab + (size_t)slice * 96 * 256;
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[(size_t)(16 * a + 4 * kq + r) * 256 + 64 * wv + 16 * t + col] = acc[a][t][r];
+    if (wv == 0) {
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            float v = bsum[a];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (kq == 0) bias_slab[(size_t)slice * 96 + 16 * a + col] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void conv9x9_c3_wgrad_reduce_kernel(const float* __restrict__ slab,
+                                                                      const float* __restrict__ bias_slab, int slices,
+                                                                      float* __restrict__ r, float* __restrict__ dbias)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;              // over c * 256 + j
+    if (idx < 96 * 256) {
+        const int c = idx >> 8, j = idx & 255;
+        if (j < 243) {
+            float s0 = 0.f, s1 = 0.f;
+            int sl = 0;
+            for (; sl + 1 < slices; sl += 2) {
+                s0 += slab[(size_t)sl * 96 * 256 + idx];
+                s1 += slab[(size_t)(sl + 1) * 96 * 256 + idx];
+            }
+            if (sl < slices) s0 += slab[(size_t)sl * 96 * 256 + idx];
+            r[c * 243 + j] = s0 + s1;
+        }
+    }
+    if (dbias && idx < 96) {
+        float s = 0.f;
+        for (int sl = 0; sl < slices; ++sl) s += bias_slab[(size_t)sl * 96 + idx];
+        dbias[idx] = s;
+    }
+}
+
+static int wgrad9_slices(int total_rows) { return total_rows < 1024 ? (total_rows + 3) / 4 : 256; }
+
+size_t conv9x9_c3_wgrad_scratch_bytes(int n, int ah)
+{
+    const int slices = wgrad9_slices(n * ah);
+    return ((size_t)slices * 96 * 256 + (size_t)slices * 96) * sizeof(float);
+}
+
+hipError_t launch_conv9x9_c3_wgrad(const float* act, const float* img, int n, int ah, int aw, int ih, int iw, int flip, float* r,
+                                   float* dbias, void* scratch, hipStream_t s)
+{
+    const int total_rows = n * ah;
+    const int slices = wgrad9_slices(total_rows);
+    const int rps = (total_rows + slices - 1) / slices;
+    float* slab = (float*)scratch;
+    float* bias_slab = slab + (size_t)slices * 96 * 256;
+    hipLaunchKernelGGL(conv9x9_c3_wgrad_kernel, dim3((unsigned)slices), dim3(256), 0, s, act, img, total_rows, ah, aw, ih, iw, flip,
+                       rps, slab, bias_slab);
+    hipLaunchKernelGGL(conv9x9_c3_wgrad_reduce_kernel, dim3((96 * 256 + 255) / 256), dim3(256), 0, s, slab, bias_slab, slices, r,
+                       dbias);
+    return hipGetLastError();
+}
+
+// ---- ChannelAttention backward (Generator.py:15-27): y = x * s[n][c], s = sigmoid(W2 relu(W1 mean_hw(x) + b1) + b2) ------
+// pass 1: ds[n][c] = sum_hw dy * x (per image, fixed order); pass 2 (one workgroup): the two tiny FC layers backward over
+// all images (weight / bias gradients summed over the batch in image order) and dpool[n][c]; pass 3:
+// dx = dy * s + dpool / hw.
+__global__ __launch_bounds__(256) void ca_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy, int hw,
+                                                            int parts, float* __restrict__ ds_partial)
+{
+    __shared__ float red[10][96];
+    const int tid = threadIdx.x;
+    const int per = hw / parts;
+    const size_t p0 = (size_t)blockIdx.x * per;                   // blockIdx.x = image * parts + part
+    if (tid < 240) {
+        const int c4 = tid % 24, row = tid / 24;
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int p = row; p < per; p += 10) {
+            const f32x4 v = *(const f32x4*)(x + (p0 + p) * 96 + c4 * 4);
+            const f32x4 d = *(const f32x4*)(dy + (p0 + p) * 96 + c4 * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[e] += v[e] * d[e];
+        }
+        for (int e = 0; e < 4; ++e) red[row][c4 * 4 + e] = s[e];
+    }
+    __syncthreads();
+    if (tid < 96) {
+        float a = 0.f;
+        for (int r = 0; r < 10; ++r) a += red[r][tid];
+        ds_partial[(size_t)blockIdx.x * 96 + tid] = a;
+    }
+}
+
+// one workgroup of 256 threads; loops over the images
+__global__ __launch_bounds__(256) void ca_bwd_fc_kernel(const float* __restrict__ pool_partial, const float* __restrict__ ds_partial,
+                                                        int n, int parts, int hw, const float* __restrict__ w1,
+                                                        const float* __restrict__ b1, const float* __restrict__ w2,
+                                                        const float* __restrict__ b2, const float* __restrict__ scale,
+                                                        float* __restrict__ dpool, float* __restrict__ dw1, float* __restrict__ db1,
+                                                        float* __restrict__ dw2, float* __restrict__ db2)
+{
+    __shared__ float pool[96], hid[12], pre[12], dq[96], dh[12];
+    const int tid = threadIdx.x;
+    // thread-owned gradient entries: dw2[c][r] (96 x 12 = 1152) and dw1[r][c] (12 x 96 = 1152): 4.5 per thread each
+    float g2[5] = {0, 0, 0, 0, 0}, g1[5] = {0, 0, 0, 0, 0};
+    float gb2 = 0.f, gb1 = 0.f;
+    for (int img = 0; img < n; ++img) {
+        if (tid < 96) {
+            float p = 0.f, d = 0.f;
+            for (int t = 0; t < parts; ++t) {
+                p += pool_partial[((size_t)img * parts + t) * 96 + tid];
+                d += ds_partial[((size_t)img * parts + t) * 96 + tid];
+            }
+            pool[tid] = p / (float)hw;
+            const float sc = scale[(size_t)img * 96 + tid];
+            dq[tid] = d * sc * (1.f - sc);                        // through the sigmoid
+        }
+        __syncthreads();
+        if (tid < 12) {
+            float a = b1[tid];
+            for (int c = 0; c < 96; ++c) a += w1[tid * 96 + c] * pool[c];
+            pre[tid] = a;
+            hid[tid] = fmaxf(a, 0.f);
+            float g = 0.f;
+            for (int c = 0; c < 96; ++c) g += w2[c * 12 + tid] * dq[c];
+            dh[tid] = a > 0.f ? g : 0.f;                          // through the ReLU
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int i = tid + 256 * k;
+            if (i < 1152) {
+                g2[k] += dq[i / 12] * hid[i % 12];                // dw2[c][r]
+                g1[k] += dh[i / 96] * pool[i % 96];               // dw1[r][c]
+            }
+        }
+        if (tid < 96) {
+            gb2 += dq[tid];
+            float a = 0.f;
+            for (int r = 0; r < 12; ++r) a += w1[r * 96 + tid] * dh[r];
+            dpool[(size_t)img * 96 + tid] = a;
+        }
+        if (tid < 12) gb1 += dh[tid];
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const int i = tid + 256 * k;
+        if (i < 1152) { dw2[i] = g2[k]; dw1[i] = g1[k]; }
+    }
+    if (tid < 96) db2[tid] = gb2;
+    if (tid < 12) db1[tid] = gb1;
+}
+
+__global__ __launch_bounds__(256) void ca_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ scale,
+                                                           const float* __restrict__ dpool, int hw, float* __restrict__ dx, size_t n4)
+{
+    const float inv = 1.f / (float)hw;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % 24) * 4;
+        const size_t img = i / ((size_t)hw * 24);
+        f32x4 d = *(const f32x4*)(dy + i * 4);
+        const f32x4 sc = *(const f32x4*)(scale + img * 96 + c);
+        const f32x4 dp = *(const f32x4*)(dpool + img * 96 + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[e] = fmaf(d[e], sc[e], dp[e] * inv);
+        *(f32x4*)(dx + i * 4) = d;
+    }
+}
+
+hipError_t launch_chan_attn_bwd(const float* x, const float* dy, const float* pool_partial, const float* scale, int n, int hw,
+                                const float* w1, const float* b1, const float* w2, const float* b2, float* dx, float* dw1, float* db1,
+                                float* dw2, float* db2, void* scratch, hipStream_t s)
+{
+    constexpr int parts = 16;
+    float* ds_partial = (float*)scratch;                          // [n][16][96]
+    float* dpool = ds_partial + (size_t)n * parts * 96;           // [n][96]
+    hipLaunchKernelGGL(ca_bwd_reduce_kernel, dim3((unsigned)(n * parts)), dim3(256), 0, s, x, dy, hw, parts, ds_partial);
+    hipLaunchKernelGGL(ca_bwd_fc_kernel, dim3(1), dim3(256), 0, s, pool_partial, ds_partial, n, parts, hw, w1, b1, w2, b2, scale, dpool,
+                       dw1, db1, dw2, db2);
+    const size_t n4 = (size_t)n * hw * 24;
+    const size_t want = (n4 + 255) / 256;
+    hipLaunchKernelGGL(ca_bwd_apply_kernel, dim3((unsigned)(want < 16384 ? want : 16384)), dim3(256), 0, s, dy, scale, dpool, hw, dx, n4);
+    return hipGetLastError();
+}
+
+size_t chan_attn_bwd_scratch_bytes(int n) { return ((size_t)n * 16 * 96 + (size_t)n * 96) * sizeof(float); }
+
 }  // namespace srgen

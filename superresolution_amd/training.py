@@ -213,3 +213,268 @@ def resblock_backward(dout: torch.Tensor, saved: dict, block: torch.nn.Module, w
     g["block.0.weight"], g["block.0.bias"] = conv3x3_wgrad(saved["x"], dc1, ws)
     dx = conv3x3(dc1, wino_pack(seq[0].weight, mode=1), res=dout)          # + the identity branch
     return dx, g
+
+
+# ---- remaining layer types ------------------------------------------------------------------------------------------
+def prelu_scalar(x: torch.Tensor, slope: torch.Tensor) -> torch.Tensor:
+    """``nn.PReLU()`` with one slope (Generator.py:51, 9, 70), out of place (the pre-activation is kept for the backward)."""
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().srgen_prelu_scalar_fwd(x.data_ptr(), slope.data_ptr(), y.data_ptr(), x.numel(), _stream(x)))
+    return y
+
+
+def prelu_scalar_bwd(x, dy, slope, ws: Workspace, dy2=None):
+    """(dx, dslope (1,)) given the pre-activation ``x`` and ``dy`` (+ ``dy2``, a second consumer's gradient)."""
+    need = ctypes.c_size_t()
+    _lib.check(_lib.lib().srgen_prelu_scratch_bytes(ctypes.byref(need)))
+    scratch = ws.get("prelu", need.value)
+    dx = torch.empty_like(x)
+    dslope = torch.empty(1, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().srgen_prelu_scalar_bwd(x.data_ptr(), dy.data_ptr(), dy2.data_ptr() if dy2 is not None else None,
+                                                     slope.data_ptr(), dx.data_ptr(), dslope.data_ptr(), x.numel(),
+                                                     scratch.data_ptr(), scratch.numel(), _stream(x)))
+    return dx, dslope
+
+
+def conv9x9_c3(img: torch.Tensor, wm: torch.Tensor, bias, out_hw: int, flip: bool) -> torch.Tensor:
+    """out (n, out_hw, out_hw, 96) NHWC = bias + sum over the 243 taps of a 3-channel NCHW image times ``wm`` [243][96]."""
+    n, c, ih, iw = img.shape
+    assert c == 3 and img.is_contiguous() and wm.shape == (243, 96) and wm.is_contiguous()
+    out = torch.empty((n, out_hw, out_hw, 96), dtype=torch.float32, device=img.device)
+    with torch.cuda.device(img.device):
+        _lib.check(_lib.lib().srgen_conv9x9_c3_nhwc(img.data_ptr(), wm.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                                    out.data_ptr(), n, ih, iw, out_hw, out_hw, 1 if flip else 0, _stream(img)))
+    return out
+
+
+def conv9x9_c3_wgrad(act: torch.Tensor, img: torch.Tensor, ws: Workspace, flip: bool, want_bias: bool):
+    """(r (96, 243), dbias (96,) | None): r[c][j] = sum over pixels act[..., c] * tap_j(img)."""
+    _chk_nhwc("act", act)
+    n, ah = act.shape[0], act.shape[1]
+    _, c, ih, iw = img.shape
+    assert c == 3 and img.is_contiguous()
+    L = _lib.lib()
+    need = ctypes.c_size_t()
+    _lib.check(L.srgen_conv9x9_c3_wgrad_scratch_bytes(n, ah, ctypes.byref(need)))
+    scratch = ws.get("wgrad9", need.value)
+    r = torch.empty((96, 243), dtype=torch.float32, device=act.device)
+    db = torch.empty(96, dtype=torch.float32, device=act.device) if want_bias else None
+    with torch.cuda.device(act.device):
+        _lib.check(L.srgen_conv9x9_c3_wgrad(act.data_ptr(), img.data_ptr(), n, ah, ah, ih, iw, 1 if flip else 0, r.data_ptr(),
+                                            db.data_ptr() if db is not None else None, scratch.data_ptr(), scratch.numel(),
+                                            _stream(act)))
+    return r, db
+
+
+def head_pack(w: torch.Tensor) -> torch.Tensor:
+    """Weight image of the head kernel from the (3, 96, 9, 9) weight, on the device: float2 units
+    [ky 9][c8 12][u 2][h 2][n 32] with ci = 8 c8 + 4 u + 2 h + e and n = 3 kx + co (27 of 32 used).  Pure data movement."""
+    t = w.detach().permute(2, 1, 3, 0).reshape(9, 12, 2, 2, 2, 27)            # ky, (c8, u, h, e), (kx, co)
+    t = t.permute(0, 1, 2, 3, 5, 4)                                             # ky, c8, u, h, n, e
+    out = torch.zeros((9, 12, 2, 2, 32, 2), dtype=torch.float32, device=w.device)
+    out[:, :, :, :, :27, :] = t
+    return out
+
+
+def head_forward(v: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """``F.conv2d(v, w, b, padding=4)[:, :, :125, :125]`` (Generator.py:71,80): NHWC (n, 128, 128, 96) -> NCHW (n, 3, 125, 125)."""
+    _chk_nhwc("v", v)
+    n = v.shape[0]
+    y = torch.empty((n, 3, 125, 125), dtype=torch.float32, device=v.device)
+    pack = head_pack(w)
+    with torch.cuda.device(v.device):
+        _lib.check(_lib.lib().srgen_head_nhwc(v.data_ptr(), pack.data_ptr(), b.detach().data_ptr(), y.data_ptr(), n, _stream(v)))
+    return y
+
+
+def chan_attn_forward(x: torch.Tensor, ca: torch.nn.Module):
+    """``x * sigmoid(fc(mean_hw(x)))`` (Generator.py:15-27): (y, saved)."""
+    _chk_nhwc("x", x)
+    n = x.shape[0]
+    y = x.clone()                                     # the kernel scales in place; the backward needs the unscaled input
+    pool = torch.empty((n, 16, 96), dtype=torch.float32, device=x.device)
+    scale = torch.empty((n, 96), dtype=torch.float32, device=x.device)
+    fc = ca.fc
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().srgen_chan_attn_nhwc(y.data_ptr(), fc[0].weight.data_ptr(), fc[0].bias.data_ptr(),
+                                                   fc[2].weight.data_ptr(), fc[2].bias.data_ptr(), pool.data_ptr(),
+                                                   scale.data_ptr(), n, _stream(x)))
+    return y, {"x": x, "pool": pool, "scale": scale}
+
+
+def chan_attn_backward(dy: torch.Tensor, saved: dict, ca: torch.nn.Module, ws: Workspace):
+    x = saved["x"]
+    n, dev = x.shape[0], x.device
+    L = _lib.lib()
+    need = ctypes.c_size_t()
+    _lib.check(L.srgen_chan_attn_bwd_scratch_bytes(n, ctypes.byref(need)))
+    scratch = ws.get("ca", need.value)
+    fc = ca.fc
+    dx = torch.empty_like(x)
+    g = {"fc.0.weight": torch.empty((12, 96, 1, 1), dtype=torch.float32, device=dev),
+         "fc.0.bias": torch.empty(12, dtype=torch.float32, device=dev),
+         "fc.2.weight": torch.empty((96, 12, 1, 1), dtype=torch.float32, device=dev),
+         "fc.2.bias": torch.empty(96, dtype=torch.float32, device=dev)}
+    with torch.cuda.device(dev):
+        _lib.check(L.srgen_chan_attn_bwd(x.data_ptr(), dy.data_ptr(), saved["pool"].data_ptr(), saved["scale"].data_ptr(), n,
+                                         fc[0].weight.data_ptr(), fc[0].bias.data_ptr(), fc[2].weight.data_ptr(),
+                                         fc[2].bias.data_ptr(), dx.data_ptr(), g["fc.0.weight"].data_ptr(),
+                                         g["fc.0.bias"].data_ptr(), g["fc.2.weight"].data_ptr(), g["fc.2.bias"].data_ptr(),
+                                         scratch.data_ptr(), scratch.numel(), _stream(x)))
+    return dx, g
+
+
+# ---- the whole generator: forward in train mode with saved tensors, backward, optimizer step ------------------------------
+class PretrainStep:
+    """One pre-train step of the reference (``train.py:90-97``) for the drop-in ``Generator`` on one GPU:
+
+        sr = generator(lr)                                  # train mode: batch-statistics BatchNorm (Generator.py:74-80)
+        loss = weighted_l1(sr, hr) + 0.1 * (1 - ssim(sr, hr))
+        loss.backward(); optimizer.step()                   # AdamW(lr 1e-4), train.py:270
+
+    composed from the HIP operators above; gradients land in ``p.grad`` (views of ``optimizer.flat_grad``, so the
+    reference's ``grad_norm`` (train.py:23-28) and a data-parallel all-reduce of ONE 12.86 MB buffer work unchanged),
+    BatchNorm running statistics are updated as ``nn.BatchNorm2d`` does.  fp32 (see the module docstring).  With
+    ``world_size > 1`` (one process per GPU, ``torch.distributed`` initialised) ``step`` averages ``flat_grad`` over the
+    ranks with one all-reduce before the update, as DistributedDataParallel would."""
+
+    def __init__(self, generator, lr: float = 1e-4, ssim_weight: float = 0.1, l1_weight: float = 1.0, group=None):
+        p0 = next(generator.parameters())
+        if not p0.is_cuda:
+            raise RuntimeError("PretrainStep needs the generator on a ROCm device; there is no CPU fallback")
+        if generator.num_blocks != 16 or generator.base_ch != 96 or generator.in_ch != 3:
+            raise NotImplementedError("the training operators are built for Generator(16, 3, 96)")
+        self.g = generator
+        self.ws = Workspace(p0.device)
+        self.optimizer = FlatAdamW(generator.parameters(), lr=lr)
+        self.ssim_weight, self.l1_weight, self.group = ssim_weight, l1_weight, group
+        self.last_metrics = None
+
+    # -- forward ------------------------------------------------------------------------------------------------------
+    def forward(self, lr_img: torch.Tensor):
+        g, ws = self.g, self.ws
+        x = lr_img.detach().to(torch.float32).contiguous()
+        S = {"lr": x, "blocks": []}
+        stats = []                                                           # batch statistics in module order
+        w = g.input[0].weight
+        S["x1_pre"] = conv9x9_c3(x, w.detach().permute(1, 2, 3, 0).reshape(243, 96).contiguous(), g.input[0].bias.detach(), 64, False)
+        x1 = prelu_scalar(S["x1_pre"], g.input[1].weight.detach())
+        cur = x1
+        for m in g.blocks:
+            if hasattr(m, "block"):
+                cur, saved = resblock_forward(cur, m, ws)
+                stats += [saved["st1"], saved["st2"]]
+            else:
+                cur, saved = chan_attn_forward(cur, m)
+            S["blocks"].append(saved)
+        S["mid_in"] = cur
+        S["mid_c"] = conv3x3(cur, wino_pack(g.mid[0].weight), g.mid[0].bias.detach())
+        m_out, S["mid_st"] = bn_train_fwd(S["mid_c"], g.mid[1].weight.detach(), g.mid[1].bias.detach(), ws, res=x1, res_factor=1.0)
+        stats.append(S["mid_st"])
+        S["m"] = m_out
+        up = g.upsample
+        bias_p = up.conv.bias.detach().view(96, 4).t().contiguous().view(-1)      # packed block b holds channels 4c + b
+        S["u_pre"] = conv3x3(m_out, wino_pack(up.conv.weight), bias_p, cout_blocks=4, shuffle=True)
+        S["u"] = prelu_scalar(S["u_pre"], up.act.weight.detach())
+        S["v_pre"] = conv3x3(S["u"], wino_pack(g.output[0].weight), g.output[0].bias.detach())
+        S["v"] = prelu_scalar(S["v_pre"], g.output[1].weight.detach())
+        y = head_forward(S["v"], g.output[2].weight, g.output[2].bias)
+        S["stats"] = stats
+        return y, S
+
+    # -- backward -----------------------------------------------------------------------------------------------------
+    def backward(self, dsr: torch.Tensor, S: dict) -> None:
+        g, ws = self.g, self.ws
+        P = dict(g.named_parameters())
+
+        def put(key, grad):
+            P[key].grad.copy_(grad.view_as(P[key]))
+
+        # head: 9x9, 96 -> 3 (Generator.py:71), crop folded in (d out is 125 x 125)
+        w = g.output[2].weight.detach()
+        r, _ = conv9x9_c3_wgrad(S["v"], dsr, ws, flip=True, want_bias=False)      # r[ci][(co,ky,kx)]
+        put("output.2.weight", r.view(96, 3, 9, 9).permute(1, 0, 2, 3).contiguous())
+        put("output.2.bias", dsr.sum(dim=(0, 2, 3)))
+        dv = conv9x9_c3(dsr, w.permute(0, 2, 3, 1).reshape(243, 96).contiguous(), None, 128, True)
+        # output[0..1]: conv3x3 at 128 x 128 + scalar PReLU (Generator.py:69-70)
+        dv_pre, ds = prelu_scalar_bwd(S["v_pre"], dv, g.output[1].weight.detach(), ws)
+        put("output.1.weight", ds)
+        dw, db = conv3x3_wgrad(S["u"], dv_pre, ws)
+        put("output.0.weight", dw)
+        put("output.0.bias", db)
+        du = conv3x3(dv_pre, wino_pack(g.output[0].weight, mode=1))
+        # upsample: conv 96 -> 384, PixelShuffle(2), scalar PReLU (Generator.py:4-12)
+        up = g.upsample
+        du_pre, ds = prelu_scalar_bwd(S["u_pre"], du, up.act.weight.detach(), ws)
+        put("upsample.act.weight", ds)
+        n = du_pre.shape[0]
+        planes = du_pre.view(n, 64, 2, 64, 2, 96).permute(2, 4, 0, 1, 3, 5).contiguous()     # [i][j] -> (n, 64, 64, 96)
+        gw, gb = P["upsample.conv.weight"].grad.view(96, 4, 96, 3, 3), P["upsample.conv.bias"].grad.view(96, 4)
+        dm = None
+        for b in range(4):
+            pl = planes[b >> 1, b & 1]
+            dw, db = conv3x3_wgrad(S["m"], pl, ws)
+            gw[:, b].copy_(dw)
+            gb[:, b].copy_(db)
+            dm = conv3x3(pl, wino_pack(up.conv.weight, mode=1, block=b), res=dm)
+        # mid conv + BatchNorm, long skip x1 + x3 (Generator.py:61-64,78)
+        dc, dg_, db_, _ = bn_train_bwd(S["mid_c"], dm, S["mid_st"], g.mid[1].weight.detach(), g.mid[1].bias.detach(), ws)
+        put("mid.1.weight", dg_)
+        put("mid.1.bias", db_)
+        dw, db = conv3x3_wgrad(S["mid_in"], dc, ws)
+        put("mid.0.weight", dw)
+        put("mid.0.bias", db)
+        dcur = conv3x3(dc, wino_pack(g.mid[0].weight, mode=1))
+        # trunk, last module first (Generator.py:55-59)
+        for idx in range(len(g.blocks) - 1, -1, -1):
+            m, saved = g.blocks[idx], S["blocks"][idx]
+            if hasattr(m, "block"):
+                dcur, grads = resblock_backward(dcur, saved, m, ws)
+            else:
+                dcur, grads = chan_attn_backward(dcur, saved, m, ws)
+            for k, v in grads.items():
+                put(f"blocks.{idx}.{k}", v)
+        # stem: x1 feeds the trunk and the long skip (gradient dm)
+        dx1_pre, ds = prelu_scalar_bwd(S["x1_pre"], dcur, g.input[1].weight.detach(), ws, dy2=dm)
+        put("input.1.weight", ds)
+        r, db = conv9x9_c3_wgrad(dx1_pre, S["lr"], ws, flip=False, want_bias=True)
+        put("input.0.weight", r)
+        put("input.0.bias", db)
+
+    def _update_running_stats(self, S: dict, n: int) -> None:
+        bns = self.g._bn_modules()
+        m = n * 64 * 64
+        with torch.no_grad():
+            means, varis = [bn.running_mean for bn in bns], [bn.running_var for bn in bns]
+            torch._foreach_mul_(means, 0.9)
+            torch._foreach_add_(means, [st[0] for st in S["stats"]], alpha=0.1)
+            torch._foreach_mul_(varis, 0.9)
+            torch._foreach_add_(varis, [st[1] for st in S["stats"]], alpha=0.1 * m / max(m - 1, 1))
+            torch._foreach_add_([bn.num_batches_tracked for bn in bns], 1)
+
+    def forward_backward(self, lr_img: torch.Tensor, hr_img: torch.Tensor) -> torch.Tensor:
+        """Fills every ``p.grad`` and returns the loss (0-dim device tensor)."""
+        from .functional import pixel_losses
+        if not self.g.training:
+            raise RuntimeError("PretrainStep runs the generator in train mode (train.py:81): call generator.train()")
+        hr = hr_img.detach().to(torch.float32).contiguous()
+        sr, S = self.forward(lr_img)
+        vals = pixel_losses(sr, hr)                                         # [psnr, ssim, l1, weighted_l1]
+        loss = self.l1_weight * vals[3] + self.ssim_weight * (1.0 - vals[1])
+        dsr = pixel_loss_grad(sr, hr, self.ws, self.l1_weight, self.ssim_weight)
+        self.backward(dsr, S)
+        self._update_running_stats(S, sr.shape[0])
+        self.last_metrics = vals
+        return loss
+
+    def step(self, lr_img: torch.Tensor, hr_img: torch.Tensor) -> torch.Tensor:
+        import torch.distributed as dist
+        self.optimizer.zero_grad()
+        loss = self.forward_backward(lr_img, hr_img)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            dist.all_reduce(self.optimizer.flat_grad, op=dist.ReduceOp.SUM, group=self.group)       # 12.86 MB, one collective
+            self.optimizer.flat_grad.div_(dist.get_world_size(self.group))
+        self.optimizer.step()
+        return loss

@@ -14,6 +14,13 @@ integer hash of superresolution_amd/weights.py so the GPU box regenerates them).
                output on the golden inputs vs hr = synthetic seed 1: the loss value and d loss / d sr (stride-3 sample
                + sums); the same with the GAN-phase weights 1.0 / 0.3 (train.py:170-172)
   adamw_*      torch.optim.AdamW(lr=1e-4) (train.py:270 defaults) on a 4,099-element vector for three steps
+
+`python tests/golden/make_golden_bwd.py step` writes train_step.npz instead: ONE pre-train step of the real reference
+Generator (train.py:90-97 in fp32, i.e. without the bf16 autocast context: the stricter arithmetic): synthetic weights
+seed 0, lr batch = 3 dense + 1 sparse images (seed 2, as generator_train.npz), hr = synthetic seed 1,
+loss = weighted_l1 + 0.1 * (1 - ssim), loss.backward():
+  loss, sr_sample; keys = parameter names in named_parameters() order; grad_sums (n_params, 2) = {sum, sum of squares} of
+  every gradient (fp64); grad_absmax; grad_sample_<key> for a handful of tensors (stride-7 samples).
 """
 import importlib.util
 import os
@@ -108,5 +115,30 @@ def main():
     print("wrote train_ops.npz:", {k: getattr(v, "shape", None) for k, v in out.items()})
 
 
+def main_step():
+    torch.set_num_threads(8)
+    G = load_ref("ref_generator", "Generator.py")
+    U = load_ref("ref_utils", "utils.py")
+    g = G.Generator()
+    g.load_state_dict(W.synthetic_state_dict(0), strict=True)
+    g.train()
+    lr = torch.from_numpy(np.concatenate([W.synthetic_lr_batch(3, 2, "dense"), W.synthetic_lr_batch(1, 2, "sparse")], 0))
+    hr = torch.from_numpy(W.synthetic_hr_batch(4, seed=1))
+    sr = g(lr)
+    loss = weighted_l1(sr, hr) + 0.1 * (1 - U.ssim(sr, hr))
+    loss.backward()
+    names = [k for k, _ in g.named_parameters()]
+    out = {"loss": np.array(loss.item()), "sr_sample": sr.detach().flatten()[::97].numpy(), "keys": np.array(names),
+           "grad_sums": np.stack([sums(p.grad) for _, p in g.named_parameters()]),
+           "grad_absmax": np.array([p.grad.abs().max().item() for _, p in g.named_parameters()])}
+    for k in ("input.0.weight", "input.1.weight", "blocks.0.block.0.weight", "blocks.8.fc.0.weight", "blocks.8.fc.2.bias",
+              "blocks.16.block.3.weight", "blocks.17.fc.2.weight", "mid.0.weight", "mid.1.weight", "upsample.conv.weight",
+              "upsample.conv.bias", "upsample.act.weight", "output.0.weight", "output.1.weight", "output.2.weight",
+              "output.2.bias"):
+        out["grad_sample_" + k] = dict(g.named_parameters())[k].grad.flatten()[::7].numpy()
+    np.savez_compressed(os.path.join(OUT, "train_step.npz"), **out)
+    print("wrote train_step.npz: loss", loss.item(), "params", len(names))
+
+
 if __name__ == "__main__":
-    main()
+    main_step() if sys.argv[1:] == ["step"] else main()

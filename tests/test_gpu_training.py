@@ -172,3 +172,91 @@ def test_flat_adamw_vs_reference_golden(gold):
         print("adamw step", step, err)
         assert err <= 2e-7
     assert torch.equal(q.detach().cpu(), torch.zeros(7, 3))        # zero gradient, zero value: stays zero
+
+
+# ---- the whole pre-train step (train.py:90-97) ----------------------------------------------------------------------
+# Gradients at the far end of the 39-layer backward chain carry the rounding of both fp32 computations (and the odd
+# PReLU pre-activation that rounds to opposite sides of 0): measured worst 2.5e-4 of max|gradient| at the stem weight,
+# <= 1e-5 near the loss.  Bar: 1e-3 per tensor.
+GRAD_TOL = 1e-3
+def _step_batch():
+    from superresolution_amd import weights as W
+    lr = np.concatenate([W.synthetic_lr_batch(3, 2, "dense"), W.synthetic_lr_batch(1, 2, "sparse")], 0)
+    return torch.from_numpy(lr).cuda(), torch.from_numpy(W.synthetic_hr_batch(4, seed=1)).cuda()
+
+
+def _conv_bias_before_bn(key):
+    return key.endswith((".block.0.bias", ".block.3.bias")) or key == "mid.0.bias"
+
+
+def test_pretrain_step_gradients_vs_reference_golden():
+    """One pre-train step of the REAL reference generator (fp32; make_golden_bwd.py step): the loss, the output and the
+    gradient of all 167 parameter tensors (checksums for every tensor, samples for sixteen of them)."""
+    from superresolution_amd import Generator, training as T, weights as W
+    gs = np.load(os.path.join(GOLDEN, "train_step.npz"))
+    g = Generator()
+    g.load_state_dict(W.synthetic_state_dict(0))
+    g = g.cuda().train()
+    step = T.PretrainStep(g, lr=1e-4)
+    lr, hr = _step_batch()
+    loss = step.forward_backward(lr, hr)
+    assert abs(float(loss) - float(gs["loss"])) <= 1e-5 * abs(float(gs["loss"]))
+    names = [k for k, _ in g.named_parameters()]
+    assert names == [str(k) for k in gs["keys"]]
+    P = dict(g.named_parameters())
+    scale_all = float(gs["grad_absmax"].max())
+    worst = 0.0
+    for i, k in enumerate(names):
+        gr = P[k].grad.detach().double().cpu()
+        ref_sum, ref_sq = gs["grad_sums"][i]
+        if _conv_bias_before_bn(k):
+            # true gradient 0 (the BatchNorm behind it removes the mean): both sides hold rounding residue
+            assert float(gr.abs().max()) <= 1e-4 * scale_all, k
+            continue
+        n = gr.numel()
+        e_sq = abs(float((gr * gr).sum()) - ref_sq) / max(ref_sq, 1e-30)
+        e_sum = abs(float(gr.sum()) - ref_sum) / max(np.sqrt(n * ref_sq), 1e-30)
+        worst = max(worst, e_sq, e_sum)
+        assert e_sq <= 2 * GRAD_TOL and e_sum <= GRAD_TOL, (k, e_sq, e_sum)
+        sk = "grad_sample_" + k
+        if sk in gs.files:
+            e = max_rel(gr.flatten()[::7].numpy(), gs[sk])
+            worst = max(worst, e)
+            print("  grad sample", k, e)
+            assert e <= GRAD_TOL, (k, e)
+    print("pre-train step: worst gradient error vs the reference", worst)
+
+
+def test_pretrain_step_updates_parameters_and_running_stats():
+    """step(): AdamW applied to the gradients just computed (checked against torch.optim.AdamW fed the same gradients),
+    BatchNorm running statistics as the train-mode forward fixture has them, loss decreases over a few steps."""
+    from superresolution_amd import Generator, training as T, weights as W
+    gt = np.load(os.path.join(GOLDEN, "generator_train.npz"))
+    g = Generator()
+    g.load_state_dict(W.synthetic_state_dict(0))
+    g = g.cuda().train()
+    step = T.PretrainStep(g, lr=1e-4)
+    lr, hr = _step_batch()
+    before = {k: p.detach().clone() for k, p in g.named_parameters()}
+    loss0 = float(step.step(lr, hr))
+    grads = {k: p.grad.detach().clone() for k, p in g.named_parameters()}
+    ref = {k: torch.nn.Parameter(v.clone()) for k, v in before.items()}
+    opt = torch.optim.AdamW(list(ref.values()), lr=1e-4)
+    for k, p in ref.items():
+        p.grad = grads[k]
+    opt.step()
+    for k, p in g.named_parameters():
+        assert float((p.detach() - ref[k].detach()).abs().max()) <= 2e-7, k
+    sd = g.state_dict()
+    keys = [str(k) for k in gt["bn_keys"]]
+    em = max(np.abs(sd[k + ".running_mean"].cpu().numpy() - gt["mean1"][i]).max() for i, k in enumerate(keys))
+    ev = max(max_rel(sd[k + ".running_var"].cpu().numpy(), gt["var1"][i]) for i, k in enumerate(keys))
+    assert em <= 1e-5 and ev <= 1e-5                      # same batch as generator_train.npz's first forward
+    assert int(sd[keys[0] + ".num_batches_tracked"]) == 1001
+    losses = [loss0] + [float(step.step(lr, hr)) for _ in range(4)]
+    print("pre-train losses over 5 steps on one batch:", losses)
+    assert losses[-1] < losses[0]
+    # the eval forward picks the updated weights up (re-fold from the stepped parameters)
+    with torch.no_grad():
+        y = g.eval()(lr)
+    assert torch.isfinite(y).all()
