@@ -15,6 +15,7 @@
 namespace srgen {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // ---- Winograd weight image on the device ---------------------------------------------------------------
 // Layout of srgen_conv3x3_f32_wino.hip (srgen_api.cpp pack3x3_wino_f32): float4 units
@@ -59,98 +60,123 @@ hipError_t launch_wino_pack(const float* w, float* out, int cout_total, int mode
 
 // ---- conv3x3 weight gradient ------------------------------------------------------------------------------
 // dW[co][ci][ky][kx] = sum over pixels dY[n][y][x][co] * X[n][y+ky-1][x+kx-1][ci] (zero outside the image).
-// A GEMM with M = co, N = ci, K = pixels per tap.  Workgroup = (tap, slice of image rows), 4 waves as a 2 x 2
-// grid of 48 co x 48 ci (3 x 3 tiles of v_mfma_f32_16x16x4_f32: A = dY^T with lane (i, kq) holding
-// dY[pixel kq][co i], B = X with lane (kq, j) holding X[shifted pixel kq][ci j]; both straight from the NHWC
-// tensors, 64-byte runs per pixel).  Partial sums go to a slab [slice][tap][co][ci]; a second kernel adds the
-// slices in fixed order (bitwise reproducible) and transposes to OIHW.  The centre-tap workgroups also
-// produce the bias gradient sum_pixels dY.
-__global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                            int total_rows, int H, int W, int rows_per_slice,
+// A GEMM with M = co, N = ci, K = pixels per tap.  Workgroup = (tap, slice of image rows), 3 waves, wave w owning
+// co [32w, 32w+32) x all 96 ci as 2 x 6 tiles of v_mfma_f32_16x16x4_f32.  Operands come straight from the NHWC
+// tensors with one wide load per lane: A = dY^T, lane (i, kq) loads dY[pixel kq][32w + 2i .. +1] (8 bytes; tile a
+// has row i = channel 32w + 2i + a), B = X, lane (kq, j) loads X[shifted pixel kq][4j .. 4j+3] and [64 + 2j .. +1]
+// (tiles 0-3: column j = channel 4j + b, tiles 4-5: 64 + 2j + b - 4).  The channel permutation is undone when the
+// partial sums are stored to the slab [slice][tap][co][ci]; a second kernel adds the slices in fixed order
+// (bitwise reproducible) and transposes to OIHW.  The nine taps of a slice are consecutive workgroups of ONE XCD
+// (blockIdx % 8), so X and dY come from HBM once and from that XCD's L2 eight more times.  The centre-tap
+// workgroups also produce the bias gradient sum_pixels dY.
+__global__ __launch_bounds__(192) void conv3x3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            int total_rows, int H, int W, int rows_per_slice, int slices,
                                                             float* __restrict__ slab, float* __restrict__ bias_slab)
 {
-    const int tap = blockIdx.x % 9, slice = blockIdx.x / 9;
+    int tap, slice;
+    if ((slices & 7) == 0) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        tap = j % 9;
+        slice = (j / 9) * 8 + xcd;
+    } else {
+        tap = blockIdx.x % 9;
+        slice = blockIdx.x / 9;
+    }
     const int ky = tap / 3, kx = tap % 3;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int wr = wv >> 1, wc = wv & 1;
     const int i = lane & 15, kq = lane >> 4;
-    f32x4 acc[3][3];
+    f32x4 acc[2][6];
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 3; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float bsum[3] = {0.f, 0.f, 0.f};
+        for (int b = 0; b < 6; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum[2] = {0.f, 0.f};
     const int r0 = slice * rows_per_slice;
     const int r1 = min(r0 + rows_per_slice, total_rows);
     for (int row = r0; row < r1; ++row) {
         const int yy = row % H;                       // row = n * H + y
         const int ys = yy + ky - 1;
         if ((unsigned)ys >= (unsigned)H) continue;    // the shifted row lies outside the image: contributes zero
-        const float* dyr = dy + (size_t)row * W * 96 + 48 * wr + i;
-        const float* xr = x + ((size_t)(row + ky - 1) * W + (kx - 1)) * 96 + 48 * wc + i;
+        const float* dyr = dy + (size_t)row * W * 96 + 32 * wv + 2 * i;
+        const float* xr = x + ((size_t)(row + ky - 1) * W + (kx - 1)) * 96;
         for (int x0 = 0; x0 < W; x0 += 4) {
             const int px = x0 + kq;
             const int xs = px + kx - 1;
             const bool ok = (unsigned)xs < (unsigned)W;
-            float av[3], bv[3];
+            const f32x2 av = *(const f32x2*)(dyr + (size_t)px * 96);
+            f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x2 b2 = f32x2{0.f, 0.f};
+            if (ok) {
+                b4 = *(const f32x4*)(xr + (size_t)px * 96 + 4 * i);
+                b2 = *(const f32x2*)(xr + (size_t)px * 96 + 64 + 2 * i);
+            }
 #pragma unroll
-            for (int a = 0; a < 3; ++a) av[a] = dyr[(size_t)px * 96 + 16 * a];
-#pragma unroll
-            for (int b = 0; b < 3; ++b) bv[b] = ok ? xr[(size_t)px * 96 + 16 * b] : 0.f;
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
+            for (int a = 0; a < 2; ++a) {
                 bsum[a] += av[a];
 #pragma unroll
-                for (int b = 0; b < 3; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+                for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], b4[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[a][4 + b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], b2[b], acc[a][4 + b], 0, 0, 0);
             }
         }
     }
-    // D[row = 4*(lane>>4) + r][col = lane & 15]
+    // D[row = 4*(lane>>4) + r][col = lane & 15]; row -> co = 32w + 2 row + a, col -> ci as above
     float* o = slab + ((size_t)slice * 9 + tap) * 96 * 96;
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 3; ++b)
+        for (int r = 0; r < 4; ++r) {
+            float* orow = o + (size_t)(32 * wv + 2 * (4 * kq + r) + a) * 96;
+            *(f32x4*)(orow + 4 * i) = f32x4{acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]};
+            *(f32x2*)(orow + 64 + 2 * i) = f32x2{acc[a][4][r], acc[a][5][r]};
+        }
+    if (tap == 4) {                                   // every row is visited by the centre tap (ys = yy)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                o[(size_t)(48 * wr + 16 * a + 4 * kq + r) * 96 + 48 * wc + 16 * b + i] = acc[a][b][r];
-    if (tap == 4 && wc == 0) {                        // every row is visited by the centre tap (ys = yy)
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
+        for (int a = 0; a < 2; ++a) {
             float v = bsum[a];
             v += __shfl_xor(v, 16);
             v += __shfl_xor(v, 32);
-            if (kq == 0) bias_slab[(size_t)slice * 96 + 48 * wr + 16 * a + i] = v;
+            if (kq == 0) bias_slab[(size_t)slice * 96 + 32 * wv + 2 * i + a] = v;
         }
     }
 }
 
+// 64 outputs x 4 slice groups per block; group g adds slices g, g+4, ... (four loads in flight), LDS joins the groups
 __global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const float* __restrict__ slab,
                                                                    const float* __restrict__ bias_slab, int slices,
                                                                    float* __restrict__ dw, float* __restrict__ dbias)
 {
-    const int idx = blockIdx.x * 256 + threadIdx.x;          // over tap * 9216 + co * 96 + ci
-    if (idx < 9 * 96 * 96) {
-        const int tap = idx / 9216, rem = idx % 9216;
+    __shared__ float part[4][64];
+    const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + o;                     // over tap * 9216 + co * 96 + ci  (9 * 9216 = 1296 * 64)
+    const int tap = idx / 9216, rem = idx % 9216;
+    {
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        int sl = 0;
-        for (; sl + 3 < slices; sl += 4) {
+        int sl = g;
+        for (; sl + 12 < slices; sl += 16) {
             s0 += slab[((size_t)sl * 9 + tap) * 9216 + rem];
-            s1 += slab[((size_t)(sl + 1) * 9 + tap) * 9216 + rem];
-            s2 += slab[((size_t)(sl + 2) * 9 + tap) * 9216 + rem];
-            s3 += slab[((size_t)(sl + 3) * 9 + tap) * 9216 + rem];
+            s1 += slab[((size_t)(sl + 4) * 9 + tap) * 9216 + rem];
+            s2 += slab[((size_t)(sl + 8) * 9 + tap) * 9216 + rem];
+            s3 += slab[((size_t)(sl + 12) * 9 + tap) * 9216 + rem];
         }
-        for (; sl < slices; ++sl) s0 += slab[((size_t)sl * 9 + tap) * 9216 + rem];
-        dw[(size_t)rem * 9 + tap] = (s0 + s1) + (s2 + s3);   // (co * 96 + ci) * 9 + tap: OIHW
+        for (; sl < slices; sl += 4) s0 += slab[((size_t)sl * 9 + tap) * 9216 + rem];
+        part[g][o] = (s0 + s1) + (s2 + s3);
     }
-    if (dbias && idx < 96) {
+    __syncthreads();
+    if (g == 0) dw[(size_t)rem * 9 + tap] = (part[0][o] + part[1][o]) + (part[2][o] + part[3][o]);   // OIHW
+    if (dbias && blockIdx.x == 0 && threadIdx.x < 96) {
         float s = 0.f;
-        for (int sl = 0; sl < slices; ++sl) s += bias_slab[(size_t)sl * 96 + idx];
-        dbias[idx] = s;
+        for (int sl = 0; sl < slices; ++sl) s += bias_slab[(size_t)sl * 96 + threadIdx.x];
+        dbias[threadIdx.x] = s;
     }
 }
 
-static int wgrad_slices(int total_rows) { return total_rows < 512 ? (total_rows + 3) / 4 : 128; }
+static int wgrad_slices(int total_rows)
+{
+    static const int big = getenv("SRGEN_WGRAD_SLICES") ? atoi(getenv("SRGEN_WGRAD_SLICES")) : 128;
+    return total_rows < 4 * big ? (total_rows + 3) / 4 : big;
+}
 
 size_t conv3x3_wgrad_scratch_bytes(int n, int h)
 {
@@ -166,11 +192,11 @@ hipError_t launch_conv3x3_wgrad(const float* x, const float* dy, int n, int h, f
     const int rps = (total_rows + slices - 1) / slices;
     float* slab = (float*)scratch;
     float* bias_slab = slab + (size_t)slices * 9 * 9216;
-    hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3((unsigned)(slices * 9)), dim3(256), 0, s, x, dy, total_rows, h, h, rps,
-                       slab, bias_slab);
+    hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3((unsigned)(slices * 9)), dim3(192), 0, s, x, dy, total_rows, h, h, rps,
+                       slices, slab, bias_slab);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((9 * 9216 + 255) / 256), dim3(256), 0, s, slab, bias_slab, slices,
+    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3(9 * 9216 / 64), dim3(256), 0, s, slab, bias_slab, slices,
                        dw, dbias);
     return hipGetLastError();
 }
@@ -184,7 +210,15 @@ hipError_t launch_conv3x3_wgrad(const float* x, const float* dy, int n, int h, f
 // pass 2 (one workgroup): coefficients; pass 3: apply.  xhat and z are recomputed from the saved conv output.
 constexpr int BNB_THREADS = 240, BNB_BLOCKS = 1024;
 
-struct BnCoef { float mean, rstd, gamma, beta; };
+// per-channel constants shared by the three passes: z = c * p + q (BatchNorm output), xhat = c * rstd - mr
+__device__ __forceinline__ void bn_consts(const float* stats, const float* gamma, const float* beta, int ch, float& rstd,
+                                          float& mr, float& p, float& q)
+{
+    rstd = 1.0f / sqrtf(stats[96 + ch] + 1e-5f);
+    mr = stats[ch] * rstd;
+    p = gamma[ch] * rstd;
+    q = beta[ch] - stats[ch] * p;
+}
 
 __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* __restrict__ c, const float* __restrict__ dt,
                                                            const float* __restrict__ stats, const float* __restrict__ gamma,
@@ -195,15 +229,11 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* __restri
     const int tid = threadIdx.x;
     if (tid < BNB_THREADS) {
         const int c4 = tid % 24, row = tid / 24;
-        float mean[4], rstd[4], gm[4], bt[4], sl[4];
+        float rstd[4], mr[4], pp[4], qq[4], sl[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int ch = c4 * 4 + e;
-            mean[e] = stats[ch];
-            rstd[e] = 1.0f / sqrtf(stats[96 + ch] + 1e-5f);
-            gm[e] = gamma[ch];
-            bt[e] = beta[ch];
-            sl[e] = slope ? slope[ch] : 1.f;
+            bn_consts(stats, gamma, beta, c4 * 4 + e, rstd[e], mr[e], pp[e], qq[e]);
+            sl[e] = slope ? slope[c4 * 4 + e] : 1.f;
         }
         const size_t per = (npix + gridDim.x - 1) / gridDim.x;
         const size_t p0 = (size_t)blockIdx.x * per, p1 = p0 + per < npix ? p0 + per : npix;
@@ -213,8 +243,8 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* __restri
             const f32x4 dv = *(const f32x4*)(dt + p * 96 + c4 * 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float xh = (cv[e] - mean[e]) * rstd[e];
-                const float z = fmaf(xh, gm[e], bt[e]);
+                const float xh = fmaf(cv[e], rstd[e], -mr[e]);
+                const float z = fmaf(cv[e], pp[e], qq[e]);
                 const float d = dv[e] * dscale;
                 const bool neg = slope && z < 0.f;
                 const float dz = neg ? d * sl[e] : d;
@@ -238,53 +268,82 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* __restri
     }
 }
 
-__global__ __launch_bounds__(288) void bn_bwd_final_kernel(const double* partial, int nb, double npix,
-                                                           const float* stats, const float* gamma, float* coef /*[3][96]*/,
-                                                           float* dgamma, float* dbeta, float* dslope)
+// coef [5][96]: dc = A * dz - C - B * c with z = c * p + q deciding the PReLU branch:  {A, B, C, p, q}.
+// Block b owns channels [12b, 12b+12): 36 sums x 28 threads, each adding every 28th partial (fixed order).
+__global__ __launch_bounds__(1024) void bn_bwd_final_kernel(const double* partial, int nb, double npix,
+                                                            const float* stats, const float* gamma, const float* beta, float* coef,
+                                                            float* dgamma, float* dbeta, float* dslope)
 {
-    const int k = threadIdx.x, which = k / 96, ch = k % 96;
-    __shared__ double tot[288];
-    double a = 0.0;
-    for (int b = 0; b < nb; ++b) a += partial[(size_t)b * 288 + k];
-    tot[k] = a;
+    __shared__ double part[28][36];
+    __shared__ double tot[36];
+    const int t = threadIdx.x;
+    if (t < 1008) {
+        const int s = t % 36, q = t / 36;
+        const int k = (s / 12) * 96 + blockIdx.x * 12 + s % 12;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int b = q;
+        for (; b + 84 < nb; b += 112) {
+            a0 += partial[(size_t)b * 288 + k];
+            a1 += partial[(size_t)(b + 28) * 288 + k];
+            a2 += partial[(size_t)(b + 56) * 288 + k];
+            a3 += partial[(size_t)(b + 84) * 288 + k];
+        }
+        for (; b < nb; b += 28) a0 += partial[(size_t)b * 288 + k];
+        part[q][s] = (a0 + a1) + (a2 + a3);
+    }
     __syncthreads();
-    if (which == 0) {
+    if (t < 36) {
+        double a = 0.0;
+        for (int q = 0; q < 28; ++q) a += part[q][t];
+        tot[t] = a;
+    }
+    __syncthreads();
+    if (t < 12) {
+        const int ch = blockIdx.x * 12 + t;
         const double rstd = 1.0 / sqrt((double)stats[96 + ch] + 1e-5);
+        const double mean = (double)stats[ch];
         const double k1 = (double)gamma[ch] * rstd;
-        coef[ch] = (float)k1;                                   // dc = k1 * dz - k2 - k3 * xhat
-        coef[96 + ch] = (float)(k1 * tot[ch] / npix);
-        coef[192 + ch] = (float)(k1 * tot[96 + ch] / npix);
-        dbeta[ch] = (float)tot[ch];
-        dgamma[ch] = (float)tot[96 + ch];
-        if (dslope) dslope[ch] = (float)tot[192 + ch];
+        const double k2 = k1 * tot[t] / npix, k3 = k1 * tot[12 + t] / npix;      // dc = k1 dz - k2 - k3 xhat
+        coef[ch] = (float)k1;
+        coef[96 + ch] = (float)(k3 * rstd);
+        coef[192 + ch] = (float)(k2 - k3 * mean * rstd);
+        coef[288 + ch] = (float)k1;                                             // p = gamma * rstd
+        coef[384 + ch] = (float)((double)beta[ch] - mean * k1);                 // q
+        dbeta[ch] = (float)tot[t];
+        dgamma[ch] = (float)tot[12 + t];
+        if (dslope) dslope[ch] = (float)tot[24 + t];
     }
 }
 
+// grid * 256 is a multiple of 24, so a thread meets the same four channels at every stride: constants in registers
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ c, const float* __restrict__ dt,
-                                                           const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, const float* __restrict__ slope,
-                                                           const float* __restrict__ coef, float dscale, float* __restrict__ dc,
-                                                           size_t n4)
+                                                           const float* __restrict__ slope, const float* __restrict__ coef,
+                                                           float dscale, float* __restrict__ dc, size_t n4)
 {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-        const int ch = (int)(i % 24) * 4;
+    const size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int ch = (int)(i0 % 24) * 4;
+    float A[4], B[4], C[4], P[4], Q[4], S[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        A[e] = coef[ch + e] * dscale; B[e] = coef[96 + ch + e]; C[e] = coef[192 + ch + e];
+        P[e] = coef[288 + ch + e]; Q[e] = coef[384 + ch + e];
+        S[e] = slope ? slope[ch + e] : 1.f;
+    }
+    for (size_t i = i0; i < n4; i += (size_t)gridDim.x * 256) {
         const f32x4 cv = *(const f32x4*)(c + i * 4);
         const f32x4 dv = *(const f32x4*)(dt + i * 4);
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float rstd = 1.0f / sqrtf(stats[96 + ch + e] + 1e-5f);
-            const float xh = (cv[e] - stats[ch + e]) * rstd;
-            const float z = fmaf(xh, gamma[ch + e], beta[ch + e]);
-            const float d = dv[e] * dscale;
-            const float dz = (slope && z < 0.f) ? d * slope[ch + e] : d;
-            o[e] = coef[ch + e] * dz - coef[96 + ch + e] - coef[192 + ch + e] * xh;
+            const float z = fmaf(cv[e], P[e], Q[e]);
+            const float dz = (slope && z < 0.f) ? dv[e] * S[e] : dv[e];
+            o[e] = fmaf(A[e], dz, -C[e]) - B[e] * cv[e];
         }
         *(f32x4*)(dc + i * 4) = o;
     }
 }
 
-size_t bn_bwd_scratch_bytes() { return (size_t)BNB_BLOCKS * 288 * sizeof(double) + 288 * sizeof(float); }
+size_t bn_bwd_scratch_bytes() { return (size_t)BNB_BLOCKS * 288 * sizeof(double) + 480 * sizeof(float); }
 
 hipError_t launch_bn_train_bwd(const float* c, const float* dt, const float* stats, const float* gamma, const float* beta,
                                const float* slope, float dscale, float* dc, float* dgamma, float* dbeta, float* dslope,
@@ -294,12 +353,13 @@ hipError_t launch_bn_train_bwd(const float* c, const float* dt, const float* sta
     float* coef = (float*)(partial + (size_t)BNB_BLOCKS * 288);
     const int nb = npix < (size_t)BNB_BLOCKS * 10 ? (int)((npix + 9) / 10) : BNB_BLOCKS;
     hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(nb), dim3(256), 0, s, c, dt, stats, gamma, beta, slope, dscale, npix, partial);
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(1), dim3(288), 0, s, partial, nb, (double)npix, stats, gamma, coef, dgamma,
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(8), dim3(1024), 0, s, partial, nb, (double)npix, stats, gamma, beta, coef, dgamma,
                        dbeta, dslope);
     const size_t n4 = npix * 24;
-    const size_t want = (n4 + 255) / 256;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)(want < 16384 ? want : 16384)), dim3(256), 0, s, c, dt, stats, gamma,
-                       beta, slope, coef, dscale, dc, n4);
+    size_t want = (n4 + 255) / 256;
+    if (want > 6144) want = 6144;
+    want = (want + 2) / 3 * 3;                                   // (grid * 256) % 24 == 0
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)want), dim3(256), 0, s, c, dt, slope, coef, dscale, dc, n4);
     return hipGetLastError();
 }
 
@@ -788,65 +848,71 @@ __global__ __launch_bounds__(256) void ca_bwd_reduce_kernel(const float* __restr
     }
 }
 
-// one workgroup of 256 threads; loops over the images
-__global__ __launch_bounds__(256) void ca_bwd_fc_kernel(const float* __restrict__ pool_partial, const float* __restrict__ ds_partial,
-                                                        int n, int parts, int hw, const float* __restrict__ w1,
+// one workgroup per image: the small vectors of the two Linear layers.  vec [n][216] = {pool 96, dq 96, hid 12, dh 12}
+__global__ __launch_bounds__(128) void ca_bwd_fc_kernel(const float* __restrict__ pool_partial, const float* __restrict__ ds_partial,
+                                                        int parts, int hw, const float* __restrict__ w1,
                                                         const float* __restrict__ b1, const float* __restrict__ w2,
-                                                        const float* __restrict__ b2, const float* __restrict__ scale,
-                                                        float* __restrict__ dpool, float* __restrict__ dw1, float* __restrict__ db1,
-                                                        float* __restrict__ dw2, float* __restrict__ db2)
+                                                        const float* __restrict__ scale, float* __restrict__ dpool,
+                                                        float* __restrict__ vec)
 {
-    __shared__ float pool[96], hid[12], pre[12], dq[96], dh[12];
-    const int tid = threadIdx.x;
-    // thread-owned gradient entries: dw2[c][r] (96 x 12 = 1152) and dw1[r][c] (12 x 96 = 1152): 4.5 per thread each
-    float g2[5] = {0, 0, 0, 0, 0}, g1[5] = {0, 0, 0, 0, 0};
-    float gb2 = 0.f, gb1 = 0.f;
-    for (int img = 0; img < n; ++img) {
-        if (tid < 96) {
-            float p = 0.f, d = 0.f;
-            for (int t = 0; t < parts; ++t) {
-                p += pool_partial[((size_t)img * parts + t) * 96 + tid];
-                d += ds_partial[((size_t)img * parts + t) * 96 + tid];
-            }
-            pool[tid] = p / (float)hw;
-            const float sc = scale[(size_t)img * 96 + tid];
-            dq[tid] = d * sc * (1.f - sc);                        // through the sigmoid
+    __shared__ float pool[96], dq[96], dh[12];
+    const int tid = threadIdx.x, img = blockIdx.x;
+    float* v = vec + (size_t)img * 216;
+    if (tid < 96) {
+        float p = 0.f, d = 0.f;
+        for (int t = 0; t < parts; ++t) {
+            p += pool_partial[((size_t)img * parts + t) * 96 + tid];
+            d += ds_partial[((size_t)img * parts + t) * 96 + tid];
         }
-        __syncthreads();
-        if (tid < 12) {
-            float a = b1[tid];
-            for (int c = 0; c < 96; ++c) a += w1[tid * 96 + c] * pool[c];
-            pre[tid] = a;
-            hid[tid] = fmaxf(a, 0.f);
-            float g = 0.f;
-            for (int c = 0; c < 96; ++c) g += w2[c * 12 + tid] * dq[c];
-            dh[tid] = a > 0.f ? g : 0.f;                          // through the ReLU
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            const int i = tid + 256 * k;
-            if (i < 1152) {
-                g2[k] += dq[i / 12] * hid[i % 12];                // dw2[c][r]
-                g1[k] += dh[i / 96] * pool[i % 96];               // dw1[r][c]
-            }
-        }
-        if (tid < 96) {
-            gb2 += dq[tid];
-            float a = 0.f;
-            for (int r = 0; r < 12; ++r) a += w1[r * 96 + tid] * dh[r];
-            dpool[(size_t)img * 96 + tid] = a;
-        }
-        if (tid < 12) gb1 += dh[tid];
-        __syncthreads();
+        const float sc = scale[(size_t)img * 96 + tid];
+        pool[tid] = p / (float)hw;
+        dq[tid] = d * sc * (1.f - sc);                            // through the sigmoid
+        v[tid] = pool[tid];
+        v[96 + tid] = dq[tid];
     }
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        const int i = tid + 256 * k;
-        if (i < 1152) { dw2[i] = g2[k]; dw1[i] = g1[k]; }
+    __syncthreads();
+    if (tid < 12) {
+        float a = b1[tid];
+        for (int c = 0; c < 96; ++c) a += w1[tid * 96 + c] * pool[c];
+        float g = 0.f;
+        for (int c = 0; c < 96; ++c) g += w2[c * 12 + tid] * dq[c];
+        dh[tid] = a > 0.f ? g : 0.f;                              // through the ReLU
+        v[192 + tid] = fmaxf(a, 0.f);
+        v[204 + tid] = dh[tid];
     }
-    if (tid < 96) db2[tid] = gb2;
-    if (tid < 12) db1[tid] = gb1;
+    __syncthreads();
+    if (tid < 96) {
+        float a = 0.f;
+        for (int r = 0; r < 12; ++r) a += w1[r * 96 + tid] * dh[r];
+        dpool[(size_t)img * 96 + tid] = a;
+    }
+}
+
+// gradients of the Linear weights: entry i of dw2[c][r] / dw1[r][c] per thread, images added in index order
+__global__ __launch_bounds__(256) void ca_bwd_wgrad_kernel(const float* __restrict__ vec, int n, float* __restrict__ dw1,
+                                                           float* __restrict__ db1, float* __restrict__ dw2, float* __restrict__ db2)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < 1152) {
+        float g2 = 0.f, g1 = 0.f;
+        for (int img = 0; img < n; ++img) {
+            const float* v = vec + (size_t)img * 216;
+            g2 = fmaf(v[96 + i / 12], v[192 + i % 12], g2);       // dq[c] * hid[r]
+            g1 = fmaf(v[204 + i / 96], v[i % 96], g1);            // dh[r] * pool[c]
+        }
+        dw2[i] = g2;
+        dw1[i] = g1;
+    } else if (i < 1152 + 96) {
+        const int c = i - 1152;
+        float g = 0.f;
+        for (int img = 0; img < n; ++img) g += vec[(size_t)img * 216 + 96 + c];
+        db2[c] = g;
+    } else if (i < 1152 + 108) {
+        const int r = i - 1248;
+        float g = 0.f;
+        for (int img = 0; img < n; ++img) g += vec[(size_t)img * 216 + 204 + r];
+        db1[r] = g;
+    }
 }
 
 __global__ __launch_bounds__(256) void ca_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ scale,
@@ -873,14 +939,16 @@ hipError_t launch_chan_attn_bwd(const float* x, const float* dy, const float* po
     float* ds_partial = (float*)scratch;                          // [n][16][96]
     float* dpool = ds_partial + (size_t)n * parts * 96;           // [n][96]
     hipLaunchKernelGGL(ca_bwd_reduce_kernel, dim3((unsigned)(n * parts)), dim3(256), 0, s, x, dy, hw, parts, ds_partial);
-    hipLaunchKernelGGL(ca_bwd_fc_kernel, dim3(1), dim3(256), 0, s, pool_partial, ds_partial, n, parts, hw, w1, b1, w2, b2, scale, dpool,
-                       dw1, db1, dw2, db2);
+    float* vec = dpool + (size_t)n * 96;                          // [n][216]
+    hipLaunchKernelGGL(ca_bwd_fc_kernel, dim3((unsigned)n), dim3(128), 0, s, pool_partial, ds_partial, parts, hw, w1, b1, w2, scale,
+                       dpool, vec);
+    hipLaunchKernelGGL(ca_bwd_wgrad_kernel, dim3(5), dim3(256), 0, s, vec, n, dw1, db1, dw2, db2);
     const size_t n4 = (size_t)n * hw * 24;
     const size_t want = (n4 + 255) / 256;
     hipLaunchKernelGGL(ca_bwd_apply_kernel, dim3((unsigned)(want < 16384 ? want : 16384)), dim3(256), 0, s, dy, scale, dpool, hw, dx, n4);
     return hipGetLastError();
 }
 
-size_t chan_attn_bwd_scratch_bytes(int n) { return ((size_t)n * 16 * 96 + (size_t)n * 96) * sizeof(float); }
+size_t chan_attn_bwd_scratch_bytes(int n) { return ((size_t)n * 16 * 96 + (size_t)n * 96 + (size_t)n * 216) * sizeof(float); }
 
 }  // namespace srgen
