@@ -147,42 +147,62 @@ def pixel_loss_grad(sr: torch.Tensor, hr: torch.Tensor, ws: Workspace, w_l1: flo
     return dsr
 
 
-class FlatAdamW:
+class FlatAdamW(torch.optim.Optimizer):
     """``torch.optim.AdamW`` (train.py:270: lr 1e-4, betas (0.9, 0.999), eps 1e-8, weight decay 0.01) over ONE flat fp32
     buffer: the parameters are re-pointed at views of it, so one kernel launch updates every tensor and the data-parallel
-    gradient all-reduce of the training configurations is one collective over ``flat_grad`` (12.86 MB for the generator)."""
+    gradient all-reduce of the training configurations is one collective over ``flat_grad`` (12.86 MB for the generator).
+    A ``torch.optim.Optimizer`` with one parameter group, so the reference's ``ReduceLROnPlateau`` (train.py:76-79) and
+    ``optimizer.param_groups[0]['lr']`` (train.py:106) work on it unchanged; ``state_dict`` holds the flat moments."""
 
     def __init__(self, params, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.01):
-        self.params = [p for p in params]
-        if not self.params or not all(p.is_cuda and p.dtype == torch.float32 for p in self.params):
+        plist = [p for p in params]
+        if not plist or not all(p.is_cuda and p.dtype == torch.float32 for p in plist):
             raise RuntimeError("FlatAdamW needs fp32 parameters on a ROCm device; there is no CPU fallback")
-        dev = self.params[0].device
-        n = sum(p.numel() for p in self.params)
+        super().__init__(plist, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.params = plist
+        dev = plist[0].device
+        n = sum(p.numel() for p in plist)
         self.flat = torch.empty(n, dtype=torch.float32, device=dev)
         self.flat_grad = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg, self.exp_avg_sq = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
         off = 0
         with torch.no_grad():
-            for p in self.params:
+            for p in plist:
                 k = p.numel()
                 self.flat[off:off + k].copy_(p.detach().reshape(-1))
                 p.data = self.flat[off:off + k].view(p.shape)
                 p.grad = self.flat_grad[off:off + k].view(p.shape)
                 off += k
-        self.lr, self.betas, self.eps, self.weight_decay, self.steps = lr, betas, eps, weight_decay, 0
+        self.steps = 0
 
-    def zero_grad(self) -> None:
+    def zero_grad(self, set_to_none: bool = False) -> None:      # the gradients are views of flat_grad: never None
         self.flat_grad.zero_()
 
-    def step(self) -> None:
+    @torch.no_grad()
+    def step(self, closure=None):
+        if closure is not None:
+            raise NotImplementedError("FlatAdamW.step takes no closure")
+        g = self.param_groups[0]
         self.steps += 1
         with torch.cuda.device(self.flat.device):
             _lib.check(_lib.lib().srgen_adamw(self.flat.data_ptr(), self.flat_grad.data_ptr(), self.exp_avg.data_ptr(),
-                                              self.exp_avg_sq.data_ptr(), self.flat.numel(), float(self.lr),
-                                              float(self.betas[0]), float(self.betas[1]), float(self.eps),
-                                              float(self.weight_decay), self.steps, _stream(self.flat)))
+                                              self.exp_avg_sq.data_ptr(), self.flat.numel(), float(g["lr"]),
+                                              float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
+                                              float(g["weight_decay"]), self.steps, _stream(self.flat)))
         for p in self.params:               # in-place kernel update: tell torch the storage changed (weight re-upload)
             p.data = p.data
+
+    def state_dict(self) -> dict:
+        g = {k: v for k, v in self.param_groups[0].items() if k != "params"}
+        return {"step": self.steps, "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(), "param_groups": [g]}
+
+    def load_state_dict(self, sd: dict) -> None:
+        if sd["exp_avg"].numel() != self.flat.numel():
+            raise ValueError(f"optimizer state has {sd['exp_avg'].numel()} entries, the parameters {self.flat.numel()}")
+        self.steps = int(sd["step"])
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.param_groups[0].update(sd["param_groups"][0])
 
 
 # ---- the residual block (Generator.py:30-42) in train mode: forward with saved tensors, backward ----------------------

@@ -172,6 +172,21 @@ def test_flat_adamw_vs_reference_golden(gold):
         print("adamw step", step, err)
         assert err <= 2e-7
     assert torch.equal(q.detach().cpu(), torch.zeros(7, 3))        # zero gradient, zero value: stays zero
+    # a torch Optimizer: the reference's scheduler (train.py:76-79) and param_groups[0]['lr'] (train.py:106) drive it
+    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, mode="max", factor=0.5, patience=0, min_lr=1e-7)
+    sched.step(1.0)
+    sched.step(0.5)                                                # no improvement: lr halves
+    assert abs(opt.param_groups[0]["lr"] - 5e-5) < 1e-12
+    sd = opt.state_dict()
+    p2 = torch.nn.Parameter(p.detach().clone())
+    q2 = torch.nn.Parameter(q.detach().clone())
+    opt2 = T.FlatAdamW([p2, q2], lr=1e-4)
+    opt2.load_state_dict(sd)
+    for o, pp in ((opt, p), (opt2, p2)):
+        o.zero_grad()
+        pp.grad.copy_(_hash_tensor(99, "adamw.g", (4099,), -0.05, 0.05).cuda())
+        o.step()
+    assert torch.equal(p.detach(), p2.detach())                    # resumed optimizer continues bit for bit
 
 
 # ---- the whole pre-train step (train.py:90-97) ----------------------------------------------------------------------
