@@ -272,7 +272,7 @@ SRGEN_API int srgen_adamw(float* p, const float* g, float* m, float* v, size_t n
 /* ---- Discriminator + relativistic-average GAN loss (forward values) ------------------------
  * SURVEY.md 8(f) "next" row 3: the PatchGAN critic the reference's GAN phase evaluates on hr and on
  * generator output (train.py:145-176).  Same conventions as above; fp32 only.  These entry points
- * compute forward VALUES: the backward pass of the reference's training step is not built. */
+ * compute forward VALUES; the backward pass of the GAN step is the "GAN step operators" section below. */
 typedef struct srdisc_handle srdisc_handle;
 
 /* Discriminator(in_ch=3, base_ch=64) -- Discriminator.py:18.  This build has kernels for
@@ -313,6 +313,68 @@ SRGEN_API int srdisc_forward(srdisc_handle* h, const float* x, float* logits, vo
  * floats (device).  out2: device, {discriminator_loss, generator_loss}; stays on the device. */
 SRGEN_API int srgen_ragan_loss(const float* real, const float* fake, size_t n_real, size_t n_fake,
                                float real_label, float fake_label, float* out2, void* stream);
+
+/* ---- GAN step operators (discriminator backward, loss gradient, gradient clipping) ---------------------------------
+ * SURVEY.md 8(f) "next" row 3, backward part: what autograd does for the reference's GAN step (train.py:145-176:
+ * d_loss.backward() through both discriminator passes, g_loss.backward() through the discriminator into the
+ * generator, clip_grad_norm_).  Operators on fp32 NHWC activations, one per layer type of Discriminator.py:17-50;
+ * superresolution_amd/gan_training.py composes them.  The forward saves each layer's output out_i = lrelu(pre_i);
+ * every backward operator takes / produces dpre_i = dout_i * (out_i > 0 ? 1 : slope).  Device pointers, caller-owned
+ * scratch, nothing synchronises. */
+
+/* Replaces: the weight side of F.conv2d in Discriminator.py:9,23,35,37 for weights that change every step.
+ *   mode 0: forward pack of a (cout, cin, 3, 3) weight (cin * cout * 9 floats)
+ *   mode 1: pack of its data-gradient conv (cout -> cin channels, flipped taps; same size)
+ *   mode 2: stem pack (cin 3, cout 64; 1792 floats)      mode 3: tail pack (cout 1; 9 * cin floats) */
+SRGEN_API int srdisc_pack(const float* w_oihw, int cin, int cout, int mode, float* out, void* stream);
+
+/* Replaces: Conv2d(3, 64, 3, padding=1) + LeakyReLU (Discriminator.py:23-24) on an NCHW image, NHWC (n, h, w, 64) out. */
+SRGEN_API int srdisc_stem_nhwc(const float* x_nchw, const float* wpack, const float* bias, float* out, int n, int h,
+                               int w, float slope, void* stream);
+
+/* Replaces: DiscBlock / head.0 forward (Discriminator.py:8-11,35-36): out = lrelu(conv(in) + bias), stride 1 | 2 -- and,
+ * with a mode-1 pack, mask != NULL and stride 1, the data gradient: out = conv(in) * (mask > 0 ? 1 : slope), where in is
+ * dpre of the layer above (through srdisc_dilate2 first if that layer has stride 2), mask the saved activation below
+ * (the shape of out), bias unused.  cin, cout: multiples of 64, cin / 64 a power of two <= 8. */
+SRGEN_API int srdisc_conv_nhwc(const float* in, const float* wpack, const float* bias, const float* mask, float* out,
+                               int n, int h, int w, int cin, int cout, int stride, float slope, void* stream);
+
+/* Replaces: Conv2d(256, 1, 3, padding=1) (Discriminator.py:37): logits (n, 1, h, w). */
+SRGEN_API int srdisc_tail(const float* in, const float* wpack, const float* bias, float* logits, int n, int h, int w,
+                          int cin, void* stream);
+
+/* First half of a stride-2 layer's data gradient: out (n, h, w, c) = d (n, oh, ow, c) at even (y, x), zero elsewhere. */
+SRGEN_API int srdisc_dilate2(const float* d, float* out, int n, int oh, int ow, int h, int w, int c, void* stream);
+
+/* Replaces: weight / bias gradient of a Cin -> Cout layer: dw (cout, cin, 3, 3) OIHW, dbias [cout] (NULL to skip);
+ * in (n, h, w, cin), dpre (n, oh, ow, cout).  Fixed summation order. */
+SRGEN_API int srdisc_conv_wgrad_scratch_bytes(int n, int h, int cin, int cout, int stride, size_t* bytes);
+SRGEN_API int srdisc_conv_wgrad(const float* in, const float* dpre, int n, int h, int w, int cin, int cout, int stride,
+                                float* dw, float* dbias, void* scratch, size_t scratch_bytes, void* stream);
+
+/* Stem: weight / bias gradient (dw (64, 3, 3, 3), dbias [64]) and the gradient w.r.t. the NCHW image the discriminator
+ * was fed (the path of the adversarial loss into the generator, train.py:168-174). */
+SRGEN_API int srdisc_stem_wgrad_scratch_bytes(size_t* bytes);
+SRGEN_API int srdisc_stem_wgrad(const float* x_nchw, const float* dpre, int n, int h, int w, float* dw, float* dbias,
+                                void* scratch, size_t scratch_bytes, void* stream);
+SRGEN_API int srdisc_stem_dgrad(const float* dpre, const float* w_oihw, int n, int h, int w, float* dimg_nchw, void* stream);
+
+/* Tail backward: din (n, h, w, cin) = dpre of the layer below (act = its saved output); dw (1, cin, 3, 3) and
+ * dbias [1] when dw != NULL. */
+SRGEN_API int srdisc_tail_bwd(const float* dlogits, const float* w_oihw, const float* act, int n, int h, int w, int cin,
+                              float slope, float* din, float* dw, float* dbias, void* stream);
+
+/* Replaces: the gradient of RelativisticAverageLoss (Discriminator.py:60-72) w.r.t. its logits, times `scale`:
+ * targets (real_label, fake_label) = discriminator_loss, (0, 1) = generator_loss.  dreal may be NULL (the generator
+ * step detaches the real logits, train.py:169). */
+SRGEN_API int srgen_ragan_loss_grad(const float* real, const float* fake, size_t n_real, size_t n_fake, float target_real,
+                                    float target_fake, float scale, float* dreal, float* dfake, void* stream);
+
+/* Replaces: torch.nn.utils.clip_grad_norm_(parameters, max_norm) (train.py:175) over one flat gradient buffer:
+ * norm_coef2 = {total L2 norm, min(1, max_norm / (norm + 1e-6))}, grad *= coefficient. */
+SRGEN_API int srgen_clip_grad_norm_scratch_bytes(size_t* bytes);
+SRGEN_API int srgen_clip_grad_norm(float* grad, size_t numel, float max_norm, float* norm_coef2, void* scratch,
+                                   size_t scratch_bytes, void* stream);
 
 SRGEN_API const char* srgen_last_error(void);
 SRGEN_API int srgen_abi_version(void);

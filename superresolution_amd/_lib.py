@@ -101,6 +101,26 @@ def lib() -> ctypes.CDLL:
     L.srgen_chan_attn_nhwc.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, vp]
     L.srgen_chan_attn_bwd_scratch_bytes.argtypes = [i, ctypes.POINTER(sz)]
     L.srgen_chan_attn_bwd.argtypes = [vp, vp, vp, vp, i, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
+    psz = ctypes.POINTER(sz)
+    L.srdisc_pack.argtypes = [vp, i, i, i, vp, vp]
+    L.srdisc_stem_nhwc.argtypes = [vp, vp, vp, vp, i, i, i, f, vp]
+    L.srdisc_conv_nhwc.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, f, vp]
+    L.srdisc_tail.argtypes = [vp, vp, vp, vp, i, i, i, i, vp]
+    L.srdisc_dilate2.argtypes = [vp, vp, i, i, i, i, i, i, vp]
+    L.srdisc_conv_wgrad_scratch_bytes.argtypes = [i, i, i, i, i, psz]
+    L.srdisc_conv_wgrad.argtypes = [vp, vp, i, i, i, i, i, i, vp, vp, vp, sz, vp]
+    L.srdisc_stem_wgrad_scratch_bytes.argtypes = [psz]
+    L.srdisc_stem_wgrad.argtypes = [vp, vp, i, i, i, vp, vp, vp, sz, vp]
+    L.srdisc_stem_dgrad.argtypes = [vp, vp, i, i, i, vp, vp]
+    L.srdisc_tail_bwd.argtypes = [vp, vp, vp, i, i, i, i, f, vp, vp, vp, vp]
+    L.srgen_ragan_loss_grad.argtypes = [vp, vp, sz, sz, f, f, f, vp, vp, vp]
+    L.srgen_clip_grad_norm_scratch_bytes.argtypes = [psz]
+    L.srgen_clip_grad_norm.argtypes = [vp, sz, f, vp, vp, sz, vp]
+    for name in ("srdisc_pack", "srdisc_stem_nhwc", "srdisc_conv_nhwc", "srdisc_tail", "srdisc_dilate2",
+                 "srdisc_conv_wgrad_scratch_bytes", "srdisc_conv_wgrad", "srdisc_stem_wgrad_scratch_bytes", "srdisc_stem_wgrad",
+                 "srdisc_stem_dgrad", "srdisc_tail_bwd", "srgen_ragan_loss_grad", "srgen_clip_grad_norm_scratch_bytes",
+                 "srgen_clip_grad_norm"):
+        getattr(L, name).restype = i
     for name in ("srgen_prelu_scratch_bytes", "srgen_prelu_scalar_fwd", "srgen_prelu_scalar_bwd", "srgen_conv9x9_c3_nhwc",
                  "srgen_conv9x9_c3_wgrad_scratch_bytes", "srgen_conv9x9_c3_wgrad", "srgen_head_nhwc", "srgen_chan_attn_nhwc",
                  "srgen_chan_attn_bwd_scratch_bytes", "srgen_chan_attn_bwd"):

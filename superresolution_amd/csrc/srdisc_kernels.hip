@@ -240,6 +240,20 @@ __global__ __launch_bounds__(256, G == 4 ? 1 : 2) void disc_conv_kernel(DiscConv
         for (int g = 0; g < G; ++g) {
             if (T.p[g] >= M) continue;
             float* o = a.out + (size_t)T.p[g] * a.Cout + T.cb * 64 + kq * 16;
+            if (a.mask) {
+                // data-gradient use (srdisc_train_kernels.hip): no bias; times the LeakyReLU derivative at the
+                // saved activation of the layer below, which has this output's shape
+                const float* mk = a.mask + (size_t)T.p[g] * a.Cout + T.cb * 64 + kq * 16;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const f32x4 mv = *reinterpret_cast<const f32x4*>(mk + s * 4);
+                    f32x4 r = acc[s][g];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) r[e] = mv[e] > 0.f ? r[e] : r[e] * a.slope;
+                    *reinterpret_cast<f32x4*>(o + s * 4) = r;
+                }
+                continue;
+            }
             const float* b = a.bias + T.cb * 64 + kq * 16;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {

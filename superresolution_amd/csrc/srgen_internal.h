@@ -131,6 +131,7 @@ struct DiscConvArgs {          // conv Cin -> Cout (Cin % 16 == 0, Cout % 64 == 
     int N, H, W, Cin, Cout, stride;
     float slope;               // LeakyReLU slope
     const float* zeros;        // kDiscZeroFloats zeros in device memory: what out-of-image taps read
+    const float* mask = nullptr;   // data-gradient use: (N,OH,OW,Cout) saved activation; out = acc * (mask > 0 ? 1 : slope)
 };
 constexpr int kDiscZeroFloats = 512;
 struct DiscTailArgs {          // conv Cin -> 1, stride 1, pad 1, no activation
@@ -145,6 +146,26 @@ hipError_t launch_disc_conv(const DiscConvArgs& a, hipStream_t s);
 hipError_t launch_disc_tail(const DiscTailArgs& a, hipStream_t s);
 hipError_t launch_ragan_loss(const float* real, const float* fake, size_t n_real, size_t n_fake,
                              float real_label, float fake_label, float* out2, hipStream_t s);
+
+// ---- GAN-phase backward operators (srdisc_train_kernels.hip) ---------------------------------------------------------
+// packs from live OIHW weights on the device: mode 0 forward conv, 1 data-gradient conv, 2 stem, 3 tail
+hipError_t launch_disc_pack(const float* w, float* out, int cin, int cout, int mode, hipStream_t s);
+hipError_t launch_dilate2(const float* d, float* out, int n, int oh, int ow, int h, int w, int c, hipStream_t s);
+size_t disc_wgrad_scratch_bytes(int n, int oh, int cin, int cout);
+hipError_t launch_disc_wgrad(const float* in, const float* dpre, int n, int h, int w, int cin, int cout, int stride, float* dw,
+                             float* dbias, void* scratch, hipStream_t s);
+size_t disc_stem_wgrad_scratch_bytes();
+hipError_t launch_disc_stem_wgrad(const float* img, const float* dpre, int n, int h, int w, float* dw, float* dbias, void* scratch,
+                                  hipStream_t s);
+hipError_t launch_disc_stem_dgrad(const float* dpre, const float* w, int n, int h, int wd, float* dimg, hipStream_t s);
+hipError_t launch_disc_tail_bwd(const float* dlogit, const float* w, const float* act, int n, int h, int wd, int cin, float slope,
+                                float* din, float* dw, float* db, hipStream_t s);
+hipError_t launch_ragan_grad(const float* real, const float* fake, size_t nr, size_t nf, float t_real, float t_fake, float scale,
+                             float* dreal, float* dfake, hipStream_t s);
+size_t clip_scratch_bytes();
+hipError_t launch_clip_grad_norm(float* g, size_t n, float max_norm, float* norm_coef, void* scratch, hipStream_t s);
+// per-device page of zeros (>= kDiscZeroFloats floats) kept by srgen_train_api.cpp
+int train_zero_page(const float** out);
 
 // ---- train-mode BatchNorm over an NHWC (npix, 96) fp32 tensor, in place (srgen_kernels_misc.hip) ------------
 // t <- slope ? PReLU(bn(t)) : bn(t);  then, with res: t <- res + res_factor * t.  bn uses the batch mean and

@@ -53,6 +53,16 @@ inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 }  // namespace
 
+namespace srgen {
+int train_zero_page(const float** out)
+{
+    const char* c = nullptr;
+    if (int rc = train_consts(&c)) return rc;
+    *out = reinterpret_cast<const float*>(c);
+    return SRGEN_OK;
+}
+}  // namespace srgen
+
 extern "C" {
 
 int srgen_wino_pack(const float* w_oihw, int cout_total, int mode, int block, float* out, void* stream)
