@@ -252,25 +252,28 @@ __global__ __launch_bounds__(256) void disc_stem_wgrad_kernel(const float* __res
 __global__ __launch_bounds__(256) void disc_stem_wgrad_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bias_slab,
                                                                      int parts, float* __restrict__ dw, float* __restrict__ dbias)
 {
-    const int idx = blockIdx.x * 256 + threadIdx.x;                       // co * 32 + k
-    if (idx < 64 * 32) {
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        int p = 0;
-        for (; p + 3 < parts; p += 4) {
-            s0 += slab[(size_t)p * 2048 + idx];
-            s1 += slab[(size_t)(p + 1) * 2048 + idx];
-            s2 += slab[(size_t)(p + 2) * 2048 + idx];
-            s3 += slab[(size_t)(p + 3) * 2048 + idx];
-        }
-        for (; p < parts; ++p) s0 += slab[(size_t)p * 2048 + idx];
-        const int co = idx >> 5, k = idx & 31;
-        if (k < 27) dw[((size_t)co * 3 + k % 3) * 9 + k / 3] = (s0 + s1) + (s2 + s3);
-    } else if (idx < 64 * 32 + 64) {
-        const int c = idx - 2048;
-        float s = 0.f;
-        for (int p = 0; p < parts; ++p) s += bias_slab[(size_t)p * 64 + c];
-        dbias[c] = s;
+    __shared__ float part[4][64];
+    const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + o;                                  // co * 32 + k  (blocks 0..31), bias: block 32
+    const bool is_bias = blockIdx.x == 32;
+    const float* src = is_bias ? bias_slab + o : slab + idx;
+    const size_t pitch = is_bias ? 64 : 2048;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int p = g;
+    for (; p + 12 < parts; p += 16) {
+        s0 += src[(size_t)p * pitch];
+        s1 += src[(size_t)(p + 4) * pitch];
+        s2 += src[(size_t)(p + 8) * pitch];
+        s3 += src[(size_t)(p + 12) * pitch];
     }
+    for (; p < parts; p += 4) s0 += src[(size_t)p * pitch];
+    part[g][o] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (g != 0) return;
+    const float v = (part[0][o] + part[1][o]) + (part[2][o] + part[3][o]);
+    if (is_bias) { dbias[o] = v; return; }
+    const int co = idx >> 5, k = idx & 31;
+    if (k < 27) dw[((size_t)co * 3 + k % 3) * 9 + k / 3] = v;
 }
 
 // dimg[n][ci][y][x] = sum_{tap, co} dpre[n][y - ky + 1][x - kx + 1][co] * w[co][ci][tap]  (gradient w.r.t. the image the
@@ -335,30 +338,45 @@ __global__ __launch_bounds__(256) void disc_tail_dgrad_kernel(const float* __res
     din[idx] = act[idx] > 0.f ? g : g * slope;
 }
 
-// dw[c][tap] = sum_p dlogit[p] * act[p + tap offset][c]; one workgroup per (tap, 64 channels); db = sum dlogit
-__global__ __launch_bounds__(256) void disc_tail_wgrad_kernel(const float* __restrict__ dlogit, const float* __restrict__ act, int N,
-                                                              int H, int W, int Cin, float* __restrict__ dw, float* __restrict__ db)
+// dw[c][tap] = sum_p dlogit[p] * act[p + tap offset][c]; one workgroup per (tap, 64 channels), 16 pixel groups per
+// channel joined through LDS in fixed order; db = sum dlogit (workgroup 0)
+__global__ __launch_bounds__(1024) void disc_tail_wgrad_kernel(const float* __restrict__ dlogit, const float* __restrict__ act, int N,
+                                                               int H, int W, int Cin, float* __restrict__ dw, float* __restrict__ db)
 {
-    __shared__ float red[4][64];
+    __shared__ float red[16][64];
     const int tap = blockIdx.x % 9, cb = blockIdx.x / 9;
-    const int c = cb * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    const int cl = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int c = cb * 64 + cl;
     const int ky = tap / 3, kx = tap % 3;
     const long long total = (long long)N * H * W;
     float s = 0.f;
-    for (long long p = q; p < total; p += 4) {
+    for (long long p = q; p < total; p += 16) {
         const int x = (int)(p % W);
         const int y = (int)((p / W) % H);
         const int iy = y + ky - 1, ix = x + kx - 1;
         if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
             s = fmaf(dlogit[p], act[(size_t)(p + (long long)(ky - 1) * W + (kx - 1)) * Cin + c], s);
     }
-    red[q][threadIdx.x & 63] = s;
+    red[q][cl] = s;
     __syncthreads();
-    if (q == 0) dw[(size_t)c * 9 + tap] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (q == 0) {
         float t = 0.f;
-        for (long long p = 0; p < total; ++p) t += dlogit[p];
-        db[0] = t;
+        for (int k = 0; k < 16; ++k) t += red[k][cl];
+        dw[(size_t)c * 9 + tap] = t;
+    }
+    if (blockIdx.x == 0) {
+        __syncthreads();
+        float t = 0.f;
+        for (long long p = threadIdx.x; p < total; p += 1024) t += dlogit[p];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) t += __shfl_xor(t, off);
+        if (cl == 0) red[q][0] = t;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float u = 0.f;
+            for (int k = 0; k < 16; ++k) u += red[k][0];
+            db[0] = u;
+        }
     }
 }
 
@@ -509,7 +527,7 @@ hipError_t launch_disc_stem_wgrad(const float* img, const float* dpre, int n, in
     hipLaunchKernelGGL(disc_stem_wgrad_kernel, dim3(STEMW_WGS), dim3(256), 0, s, img, dpre, n, h, w, slab, bias_slab);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(disc_stem_wgrad_reduce_kernel, dim3((2048 + 64 + 255) / 256), dim3(256), 0, s, slab, bias_slab, STEMW_WGS * 4, dw,
+    hipLaunchKernelGGL(disc_stem_wgrad_reduce_kernel, dim3(33), dim3(256), 0, s, slab, bias_slab, STEMW_WGS * 4, dw,
                        dbias);
     return hipGetLastError();
 }
@@ -528,7 +546,7 @@ hipError_t launch_disc_tail_bwd(const float* dlogit, const float* w, const float
     const size_t total = (size_t)n * h * wd * cin;
     hipLaunchKernelGGL(disc_tail_dgrad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dlogit, w, act, h, wd, cin, slope,
                        din, total);
-    if (dw) hipLaunchKernelGGL(disc_tail_wgrad_kernel, dim3((unsigned)(9 * (cin / 64))), dim3(256), 0, s, dlogit, act, n, h, wd, cin, dw, db);
+    if (dw) hipLaunchKernelGGL(disc_tail_wgrad_kernel, dim3((unsigned)(9 * (cin / 64))), dim3(1024), 0, s, dlogit, act, n, h, wd, cin, dw, db);
     return hipGetLastError();
 }
 
