@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- generator images/s (64x64 -> 125x125) on N MI355X, one process per GPU.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype f32|bf16] [--workload cfg1|cfg2]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype f32|bf16] [--workload cfg1|cfg2|cfg3|cfg4]
 
 Launching.  `--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process touches no GPU, starts
 N children of itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, 127.0.0.1 rendezvous), waits for them and
@@ -18,6 +18,9 @@ Workloads (BASELINE.json `configs`), both measured by every run and printed by r
         8 GPUs), runs them through superresolution_amd.evaluate.validate -- generator forward, the PSNR/SSIM/L1
         kernel per batch, sums kept on the device -- and ONE RCCL SUM all-reduce of {sum psnr, sum ssim, sum l1,
         batches} ends it (train.py:57-72 semantics).  `--workload cfg2` makes this leg the headline instead.
+  cfg3 / cfg4  (only with `--workload cfg3|cfg4`, a line of their own)  configs[3] / [4]: the pre-train step and the
+        GAN iteration at 64 images per GPU, fp32, data parallel: every rank steps on its own batch and one all-reduce
+        per optimizer step averages the flat gradient buffer (superresolution_amd/training.py, gan_training.py).
 
 Further objects on the line:
   roofline      dominant kernel = the 33 trunk 3x3 convs (75 % of the FLOPs).  `achieved` = FLOPs the matrix
@@ -106,13 +109,93 @@ def spawn_ranks(n, argv):
     raise SystemExit(bad[0] if bad else 0)
 
 
+def training_leg(args, dev, rank, n_ranks, use_dist):
+    """BASELINE.json configs[3] (pre-train step) / configs[4] (GAN iteration): 64 images per GPU, fp32, data parallel --
+    every rank steps on its own batch and ONE all-reduce per optimizer averages the flat gradient buffer (RCCL)."""
+    import torch
+    import torch.distributed as dist
+    from superresolution_amd import Discriminator, Generator, training as T, weights as W
+    from superresolution_amd.gan_training import GanStep
+    n = args.train_batch
+    g = Generator()
+    g.load_state_dict(W.synthetic_state_dict(0))
+    g = g.to(dev).train()
+    gen = torch.Generator(device="cpu").manual_seed(4321 + rank)
+    lr = torch.rand((n, 3, 64, 64), generator=gen).to(dev)
+    hr = torch.rand((n, 3, 125, 125), generator=gen).to(dev)
+    if args.workload == "cfg3":
+        step = T.PretrainStep(g, lr=1e-4)
+        run = lambda: step.step(lr, hr)
+        name = f"BASELINE.json configs[3]: pre-train step (forward, loss, backward, AdamW), {n} images per GPU, fp32"
+        metric = "pre-train step images/s"
+    else:
+        torch.manual_seed(3)
+        d = Discriminator().to(dev).train()
+        gan = GanStep(g, d)
+        it = [0]
+
+        def run():
+            it[0] += 1
+            return gan.step(lr, hr, update_d=(it[0] - 1) % 3 == 0)["g_loss"]      # config.py:21 discriminator_update_freq = 3
+        name = (f"BASELINE.json configs[4]: GAN iteration (discriminator half-step every 3rd iteration + generator "
+                f"half-step), {n} images per GPU, fp32")
+        metric = "GAN iteration images/s"
+
+    def barrier():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(max(args.warmup, 3)):
+        run()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = run()
+    barrier()
+    dt = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    # dominant kernel: the 3x3 weight gradient (43.5 GFLOP per launch at 64 images), timed alone with HIP events
+    ws = T.Workspace(dev)
+    xa = torch.randn((n, 64, 64, 96), device=dev)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(21)]
+    for _ in range(3):
+        T.conv3x3_wgrad(xa, xa, ws)
+    ev[0].record()
+    for i in range(20):
+        T.conv3x3_wgrad(xa, xa, ws)
+        ev[i + 1].record()
+    ev[-1].synchronize()
+    wg_ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(20))[10]
+    flop = 2.0 * n * 4096 * 96 * 864
+    if rank == 0:
+        print(json.dumps({
+            "metric": metric, "value": round(n * n_ranks * args.steps / dt, 1), "unit": "images/s", "n_gpus": n_ranks,
+            "steps": args.steps, "warmup": max(args.warmup, 3), "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": name, "batch_per_gpu": n, "global_batch": n * n_ranks, "parallelism": f"dp{n_ranks}",
+                       "collective": "one all-reduce of the flat gradient buffer per optimizer step (12.86 MB generator, "
+                                     "23.5 MB discriminator)"},
+            "loss_last": float(loss),
+            "roofline": {"bound": "mfma", "kernel": "conv3x3_wgrad_kernel + reduce (38 launches per generator backward)",
+                         "achieved": round(flop / (wg_ms * 1e-3) / 1e12, 2), "peak": 157.3, "unit": "TFLOP/s",
+                         "frac": round(flop / (wg_ms * 1e-3) / 1e12 / 157.3, 4), "traffic": None,
+                         "ms_per_launch": round(wg_ms, 4), "flop_per_launch": flop},
+            "cpu_baseline": None}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--dtype", choices=["f32", "bf16"], default=None, help="dtype of the cfg1 leg (default f32)")
-    ap.add_argument("--workload", choices=["cfg1", "cfg2"], default="cfg1", help="which leg is the headline `value`")
+    ap.add_argument("--workload", choices=["cfg1", "cfg2", "cfg3", "cfg4"], default="cfg1",
+                    help="which leg is the headline `value` (cfg3 / cfg4: the training steps, their own line)")
+    ap.add_argument("--train-batch", type=int, default=64, help="images per GPU per training step (cfg3 / cfg4)")
     ap.add_argument("--batch", type=int, default=BATCH, help="images per GPU per step (cfg1)")
     ap.add_argument("--cfg2-reps", type=int, default=5)
     ap.add_argument("--median-steps", type=int, default=50, help="HIP-event-timed steps of the median leg (>= 50)")
@@ -161,6 +244,12 @@ def main():
         if dist.get_world_size() != args.gpus:
             raise SystemExit(f"RCCL sees {dist.get_world_size()} rank(s), --gpus {args.gpus}")
     n_ranks = dist.get_world_size() if use_dist else 1
+
+    if args.workload in ("cfg3", "cfg4"):
+        training_leg(args, dev, rank, n_ranks, use_dist)
+        if use_dist:
+            dist.destroy_process_group()
+        return
 
     g = Generator()
     g.load_state_dict(W.synthetic_state_dict(0))
