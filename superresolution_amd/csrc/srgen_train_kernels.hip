@@ -345,6 +345,247 @@ __global__ __launch_bounds__(64, 2) void conv3x3_wgrad_wino_kernel(const float* 
     }
 }
 
+// ---- the same gradient with the operands staged through LDS (the default) ------------------------------------------
+// The register kernel above is bound by vector-memory instructions: each of its 24 wave types per slice loads its own
+// 8-byte pieces (11 loads per 24 MFMAs; a wave load costs the CU ~30 cycles whatever its width).  Here a workgroup of
+// four waves = (slice, nu) stages what ONE k-step (4 tiles) needs -- the 5 or 8 patch columns this nu reads x 4 rows
+// of X, the 4 or 8 pixels x 2 rows of dY, all 96 channels -- with 16-byte loads (2.6 / 4.5 per thread and k-step),
+// zero-filled outside the image, into a double-buffered LDS tile (pixel pitch 100 floats); wave (ch, cih) owns
+// 48 co x 48 ci x the four xi = 36 tiles (144 accumulators), reads its fragments with ds_read_b64 / b32
+// (ci = 48 cih + 2i + b | 48 cih + 32 + i, co likewise) and issues 36 MFMAs per k-step.  Global loads run two k-steps
+// ahead in registers (G0 / G1), the LDS write of step s+1 follows the MFMAs of step s, one barrier per k-step; two
+// workgroups per CU.  Slab / sum / final kernels are shared with the register kernel.
+#ifndef WGL_SPLIT
+#define WGL_SPLIT 0
+#endif
+constexpr int WGL_PITCH = 100;                                // LDS floats per staged pixel
+constexpr int WGL_BUF = 48 * WGL_PITCH;                       // floats per buffer: at most 32 X + 16 dY pixels
+
+template <int NU>
+__device__ __forceinline__ void wgrad_wino_lds_body(const float* __restrict__ x, const float* __restrict__ dy, int total_trows, int H,
+                                                    int W, int rows_per_slice, float* __restrict__ slab, int slice, float* lds)
+{
+    constexpr bool EDGE = NU == 0 || NU == 3;
+    constexpr int PX = EDGE ? 5 : 8, PY = EDGE ? 4 : 8;       // staged pixels per row of X / dY
+    constexpr int NX = 4 * PX * 24, NE = NX + 2 * PY * 24;    // float4 units per stage
+    constexpr int NL = (NE + 255) / 256;                      // per thread
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int ch = wv & 1, cih = wv >> 1, i = lane & 15, kq = lane >> 4;
+    const int TH = H >> 1, TW = W >> 1, spr = TW >> 2;
+    const int r0 = slice * rows_per_slice;
+    const int r1 = min(r0 + rows_per_slice, total_trows);
+    const int nst = (r1 > r0 ? r1 - r0 : 0) * spr;
+
+    // what this thread stages: unit e = tid + 256 k, packed as row+1 | (col+1) << 2 | c4 << 7 | isx << 12 | on << 13
+    int s_pk[NL], s_lds[NL];
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+        const int e = tid + 256 * k;
+        const bool on = e < NE, isx = e < NX;
+        const int u = isx ? e : (on ? e - NX : 0);
+        const int c4 = u % 24, slot = (u / 24) % (isx ? PX : PY), rr = u / (24 * (isx ? PX : PY));
+        const int col = isx ? (NU == 0 ? 2 * slot : NU == 3 ? 2 * slot + 1 : slot + 1) - 1        // column - 2 tx0
+                            : (NU == 0 ? 2 * slot : NU == 3 ? 2 * slot + 1 : slot);
+        const int row = isx ? rr - 1 : rr;                                                      // row - 2 ty
+        s_pk[k] = (row + 1) | (col + 1) << 2 | c4 << 7 | (int)isx << 12 | (int)on << 13;
+        s_lds[k] = ((isx ? rr * PX : 4 * PX + rr * PY) + slot) * WGL_PITCH + 4 * c4;
+    }
+    f32x4 G0[NL], G1[NL];
+    unsigned m0 = 0, m1 = 0;                                  // bit k: unit k of that buffer lies inside the image
+    // float offset of unit k from pixel (2 ty - 1, 2 tx0 - 1) of its tensor: all an interior k-step needs per load
+    unsigned s_off[NL];
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+        const int pk = s_pk[k];
+        s_off[k] = (unsigned)(((pk & 3) * W + ((pk >> 2) & 31)) * 96 + 4 * ((pk >> 7) & 31));
+    }
+    auto issue = [&](f32x4 (&G)[NL], unsigned& mask, int sg) {
+        const int trow = r0 + sg / spr;
+        const int n = trow / TH, ty = trow - n * TH, tx0 = (sg % spr) * 4;
+        if (ty > 0 && ty < TH - 1 && tx0 > 0 && tx0 < TW - 4) {          // wave-uniform: nothing can leave the image
+            const size_t uni = (((size_t)n * H + 2 * ty - 1) * W + 2 * tx0 - 1) * 96;
+            const float* bx = x + uni;
+            const float* by = dy + uni;
+#pragma unroll
+            for (int k = 0; k < NL; ++k) G[k] = *(const f32x4*)(((s_pk[k] >> 12) & 1 ? bx : by) + s_off[k]);
+            mask = ~0u;
+            return;
+        }
+        mask = 0;
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            const int pk = s_pk[k];
+            const int y = 2 * ty + (pk & 3) - 1, c = 2 * tx0 + ((pk >> 2) & 31) - 1;
+            const bool v = (pk >> 13) && (unsigned)y < (unsigned)H && (unsigned)c < (unsigned)W;
+            const float* base = (pk >> 12) & 1 ? x : dy;
+            G[k] = *(const f32x4*)(base + (((size_t)n * H + (v ? y : 0)) * W + (v ? c : 0)) * 96 + 4 * ((pk >> 7) & 31));
+            mask |= (unsigned)v << k;
+        }
+    };
+    // zero fill outside the image happens HERE (the consumer side of the loads), not in issue()
+    auto commit = [&](const f32x4 (&G)[NL], unsigned mask, float* buf) {
+#pragma unroll
+        for (int k = 0; k < NL; ++k)
+            if (s_pk[k] >> 13) *(f32x4*)(buf + s_lds[k]) = G[k] * (((mask >> k) & 1u) ? 1.f : 0.f);
+    };
+
+    f32x4 acc[4][3][3];
+#pragma unroll
+    for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) acc[xi][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum[3] = {0.f, 0.f, 0.f};
+
+    // fragment addresses of tile kq: X slots of the two columns, dY slots
+    const int sa = EDGE ? kq : (NU == 1 ? 2 * kq : 2 * kq + 1), sb = EDGE ? kq + 1 : (NU == 1 ? 2 * kq + 1 : 2 * kq);
+    const int xfrag = 48 * cih + 2 * i, xfrag2 = 48 * cih + 32 + i;
+    const int yfrag = 48 * ch + 2 * i, yfrag2 = 48 * ch + 32 + i;
+    // raw fragments of one k-step
+    f32x2 Fa2[4], Fb2[4], Fg2[2], Fh2[2];
+    float Fa1[4], Fb1[4], Fg1[2], Fh1[2];
+    auto read_frag = [&](const float* buf) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float* pa = buf + (r * PX + sa) * WGL_PITCH;
+            const float* pb = buf + (r * PX + sb) * WGL_PITCH;
+            Fa2[r] = *(const f32x2*)(pa + xfrag); Fb2[r] = *(const f32x2*)(pb + xfrag);
+            Fa1[r] = pa[xfrag2]; Fb1[r] = pb[xfrag2];
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const float* q0 = buf + (4 * PX + a * PY + (EDGE ? kq : 2 * kq)) * WGL_PITCH;
+            Fg2[a] = *(const f32x2*)(q0 + yfrag); Fg1[a] = q0[yfrag2];
+            if (!EDGE) { Fh2[a] = *(const f32x2*)(q0 + WGL_PITCH + yfrag); Fh1[a] = q0[WGL_PITCH + yfrag2]; }
+        }
+    };
+    float xh[4][3], yh[4][3];
+    auto transform = [&]() {
+        float w[4][3];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (NU == 1) { w[r][0] = Fa2[r][0] + Fb2[r][0]; w[r][1] = Fa2[r][1] + Fb2[r][1]; w[r][2] = Fa1[r] + Fb1[r]; }
+            else { w[r][0] = Fa2[r][0] - Fb2[r][0]; w[r][1] = Fa2[r][1] - Fb2[r][1]; w[r][2] = Fa1[r] - Fb1[r]; }
+        }
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            xh[0][e] = w[0][e] - w[2][e]; xh[1][e] = w[1][e] + w[2][e]; xh[2][e] = w[2][e] - w[1][e]; xh[3][e] = w[1][e] - w[3][e];
+        }
+        float c[2][3];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            if (EDGE) { c[a][0] = Fg2[a][0]; c[a][1] = Fg2[a][1]; c[a][2] = Fg1[a]; }
+            else if (NU == 1) { c[a][0] = Fg2[a][0] + Fh2[a][0]; c[a][1] = Fg2[a][1] + Fh2[a][1]; c[a][2] = Fg1[a] + Fh1[a]; }
+            else { c[a][0] = Fg2[a][0] - Fh2[a][0]; c[a][1] = Fg2[a][1] - Fh2[a][1]; c[a][2] = Fg1[a] - Fh1[a]; }
+        }
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            yh[0][e] = c[0][e]; yh[1][e] = c[0][e] + c[1][e]; yh[2][e] = c[0][e] - c[1][e]; yh[3][e] = c[1][e];
+        }
+    };
+    auto mfmas = [&]() {
+        if (NU == 1) {
+#pragma unroll
+            for (int e = 0; e < 3; ++e) bsum[e] += yh[1][e];
+        }
+#pragma unroll
+        for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b)
+                    acc[xi][a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(yh[xi][a], xh[xi][b], acc[xi][a][b], 0, 0, 0);
+    };
+
+    // LDS-only barrier: __syncthreads() also waits vmcnt(0), which would bring the prefetched global loads home at every
+    // k-step.  lgkmcnt(0) = this wave's ds_writes are done (and its ds_reads have returned).
+    auto lds_barrier = [] {
+        __builtin_amdgcn_s_waitcnt(0xC07F);                   // vmcnt(63) expcnt(7) lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    // Per k-step: global loads two steps ahead -> registers; fragments of this step from LDS, transforms, 36 MFMAs; the
+    // next step's staged registers -> the other LDS buffer; barrier.  (A three-stage variant that reads the next step's
+    // fragments under the MFMAs needs 36 more registers: it spilled at two workgroups per CU and, at one, ran 407 us
+    // against 292.)
+    float* buf0 = lds;
+    float* buf1 = lds + WGL_BUF;
+    auto clampst = [&](int sg) { return sg < nst ? sg : nst - 1; };
+    if (nst > 0) {                                            // nst is even (W % 16 == 0), uniform over the workgroup
+        issue(G0, m0, 0);
+        issue(G1, m1, 1);
+        commit(G0, m0, buf0);
+        lds_barrier();
+        for (int sg = 0; sg < nst; sg += 2) {
+            issue(G0, m0, clampst(sg + 2));
+            __builtin_amdgcn_sched_barrier(0);
+            read_frag(buf0);
+            transform();
+            if (WGL_SPLIT) __builtin_amdgcn_sched_barrier(0);
+            mfmas();
+            __builtin_amdgcn_sched_barrier(0);
+            commit(G1, m1, buf1);
+            lds_barrier();
+            issue(G1, m1, clampst(sg + 3));
+            __builtin_amdgcn_sched_barrier(0);
+            read_frag(buf1);
+            transform();
+            if (WGL_SPLIT) __builtin_amdgcn_sched_barrier(0);
+            mfmas();
+            __builtin_amdgcn_sched_barrier(0);
+            commit(G0, m0, buf0);
+            lds_barrier();
+        }
+    }
+    // D[row = 4*kq + r][col = i]: row -> co = 48 ch + 2 row + a (a < 2) | 48 ch + 32 + row; col -> ci likewise with cih
+#pragma unroll
+    for (int xi = 0; xi < 4; ++xi) {
+        float* o = slab + (size_t)slice * kWgSliceFloats + (size_t)(xi * 4 + NU) * 9216;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * kq + r;
+                float* orow = o + (size_t)(48 * ch + (a < 2 ? 2 * row + a : 32 + row)) * 96;
+                *(f32x2*)(orow + xfrag) = f32x2{acc[xi][a][0][r], acc[xi][a][1][r]};
+                orow[xfrag2] = acc[xi][a][2][r];
+            }
+    }
+    if (NU == 1 && cih == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            float v = bsum[a];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (kq == 0) slab[(size_t)slice * kWgSliceFloats + 147456 + (a < 2 ? yfrag + a : yfrag2)] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_wino_lds_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                       int total_trows, int H, int W, int rows_per_slice,
+                                                                       float* __restrict__ slab)
+{
+    __shared__ __attribute__((aligned(16))) float lds[2 * WGL_BUF];
+    // the four nu of a slice are consecutive workgroups of one XCD (blockIdx % 8)
+    int b = blockIdx.x, slice;
+    if ((gridDim.x / 4) % 8 == 0) {
+        const int xcd = b & 7, j = b >> 3;
+        slice = (j / 4) * 8 + xcd;
+        b = j % 4;
+    } else {
+        slice = b / 4;
+        b = b % 4;
+    }
+    switch (b) {                                              // workgroup-uniform
+    case 0: wgrad_wino_lds_body<0>(x, dy, total_trows, H, W, rows_per_slice, slab, slice, lds); break;
+    case 1: wgrad_wino_lds_body<1>(x, dy, total_trows, H, W, rows_per_slice, slab, slice, lds); break;
+    case 2: wgrad_wino_lds_body<2>(x, dy, total_trows, H, W, rows_per_slice, slab, slice, lds); break;
+    default: wgrad_wino_lds_body<3>(x, dy, total_trows, H, W, rows_per_slice, slab, slice, lds); break;
+    }
+}
+
 // M[pos][co][ci] (and the bias partials behind them) = sum over slices, fixed order: 64 entries x 4 slice groups per
 // block (grid: kWgSliceFloats / 64 blocks; the pad entries are summed too and never read)
 __global__ __launch_bounds__(256) void wino_wgrad_sum_kernel(const float* __restrict__ slab, int slices, float* __restrict__ m)
@@ -413,11 +654,24 @@ static bool wgrad_direct()
     return direct;
 }
 
+static bool wgrad_reg()
+{
+    static const bool reg = getenv("SRGEN_WGRAD") && !strcmp(getenv("SRGEN_WGRAD"), "reg");
+    return reg;
+}
+
+static int wgrad_lds_slices(int total_trows)
+{
+    static const int big = getenv("SRGEN_WGRAD_LDS_SLICES") ? atoi(getenv("SRGEN_WGRAD_LDS_SLICES")) : 128;
+    return total_trows < 2 * big ? (total_trows + 1) / 2 : big;
+}
+
 size_t conv3x3_wgrad_scratch_bytes(int n, int h)
 {
     const int slices = wgrad_slices(n * h);
     const size_t direct = ((size_t)slices * 9 * 9216 + (size_t)slices * 96) * sizeof(float);
-    const int ws = wgrad_wino_slices(n * (h / 2));
+    int ws = wgrad_wino_slices(n * (h / 2));
+    if (wgrad_lds_slices(n * (h / 2)) > ws) ws = wgrad_lds_slices(n * (h / 2));
     const size_t wino = ((size_t)ws + 1) * kWgSliceFloats * sizeof(float);
     return direct > wino ? direct : wino;
 }
@@ -425,6 +679,20 @@ size_t conv3x3_wgrad_scratch_bytes(int n, int h)
 hipError_t launch_conv3x3_wgrad(const float* x, const float* dy, int n, int h, float* dw, float* dbias, void* scratch,
                                 hipStream_t s)
 {
+    if (!wgrad_direct() && !wgrad_reg() && h % 16 == 0) {
+        const int total_trows = n * (h / 2);
+        const int slices = wgrad_lds_slices(total_trows);
+        const int rps = (total_trows + slices - 1) / slices;
+        float* slab = (float*)scratch;
+        float* m = slab + (size_t)slices * kWgSliceFloats;
+        hipLaunchKernelGGL(conv3x3_wgrad_wino_lds_kernel, dim3((unsigned)(slices * 4)), dim3(256), 0, s, x, dy, total_trows, h, h,
+                           rps, slab);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(wino_wgrad_sum_kernel, dim3((unsigned)(kWgSliceFloats / 64)), dim3(256), 0, s, slab, slices, m);
+        hipLaunchKernelGGL(wino_wgrad_final_kernel, dim3(36), dim3(256), 0, s, m, dw, dbias);
+        return hipGetLastError();
+    }
     if (!wgrad_direct() && h % 16 == 0) {
         const int total_trows = n * (h / 2);
         const int slices = wgrad_wino_slices(total_trows);
