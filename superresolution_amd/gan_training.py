@@ -221,6 +221,10 @@ class GanStep:
     def _allreduce(self, buf: torch.Tensor) -> None:
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            if dist.get_backend(self.group) != "nccl":
+                # host-staged backends (gloo) read the buffer on the CPU side; with the backward still in flight on the
+                # stream a two-rank run on one GPU hung inside the collective one time in three (tests/test_gpu_training_dp.py)
+                torch.cuda.current_stream(buf.device).synchronize()
             dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
             buf.div_(dist.get_world_size(self.group))
 

@@ -494,6 +494,10 @@ class PretrainStep:
         self.optimizer.zero_grad()
         loss = self.forward_backward(lr_img, hr_img)
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            if dist.get_backend(self.group) != "nccl":
+                # host-staged backends (gloo) read the buffer on the CPU side; with the backward still in flight on the
+                # stream a two-rank run on one GPU was seen to hang inside the collective (tests/test_gpu_training_dp.py)
+                torch.cuda.current_stream(self.optimizer.flat_grad.device).synchronize()
             dist.all_reduce(self.optimizer.flat_grad, op=dist.ReduceOp.SUM, group=self.group)       # 12.86 MB, one collective
             self.optimizer.flat_grad.div_(dist.get_world_size(self.group))
         self.optimizer.step()
