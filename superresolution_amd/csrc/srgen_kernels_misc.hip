@@ -93,36 +93,43 @@ hipError_t launch_normalize(const float* x, void* y, size_t numel, float hr_max,
 
 // ---- bilinear resize, align_corners=False (ATen upsample_bilinear2d semantics) --------------
 // src = max(0, (dst + 0.5) * in/out - 0.5); i0 = floor(src); i1 = i0 + (i0 < in-1); l = src - i0.
-// One thread per output pixel, consecutive lanes -> consecutive ox: coalesced stores, and the
-// 2x2 gathers of neighbouring lanes fall in the same 128-byte lines.
+// A wave owns output rows (plane, oy): the row's source rows and vertical weights are wave-uniform (scalar
+// registers, no per-pixel division); lanes walk ox, so stores are coalesced and the 2x2 gathers of neighbouring
+// lanes fall in the same 128-byte lines of two source rows.
 __global__ __launch_bounds__(256) void bilinear_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                       int planes, int h, int w, int oh, int ow,
+                                                       unsigned rows, int h, int w, int oh, int ow,
                                                        float sh, float sw)
 {
-    const size_t total = (size_t)planes * oh * ow;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int ox = (int)(i % ow);
-        const size_t t = i / ow;
-        const int oy = (int)(t % oh);
-        const size_t pl = t / oh;
+    const int lane = threadIdx.x & 63;
+    const unsigned wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    for (unsigned r = wave; r < rows; r += nwaves) {          // r = plane * oh + oy
+        const unsigned pl = r / (unsigned)oh;
+        const int oy = (int)(r - pl * (unsigned)oh);
         float fy = ((float)oy + 0.5f) * sh - 0.5f; fy = fy < 0.f ? 0.f : fy;
-        float fx = ((float)ox + 0.5f) * sw - 0.5f; fx = fx < 0.f ? 0.f : fx;
-        const int y0 = (int)fy, x0 = (int)fx;
-        const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
-        const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
-        const float* xs = x + pl * h * w;
-        y[i] = hy * (hx * xs[(size_t)y0 * w + x0] + lx * xs[(size_t)y0 * w + x1]) +
-               ly * (hx * xs[(size_t)y1 * w + x0] + lx * xs[(size_t)y1 * w + x1]);
+        const int y0 = (int)fy;
+        const int y1 = y0 + (y0 < h - 1 ? 1 : 0);
+        const float ly = fy - (float)y0, hy = 1.f - ly;
+        const float* r0 = x + ((size_t)pl * h + y0) * w;
+        const float* r1 = x + ((size_t)pl * h + y1) * w;
+        float* o = y + (size_t)r * ow;
+        for (int ox = lane; ox < ow; ox += 64) {
+            float fx = ((float)ox + 0.5f) * sw - 0.5f; fx = fx < 0.f ? 0.f : fx;
+            const int x0 = (int)fx;
+            const int x1 = x0 + (x0 < w - 1 ? 1 : 0);
+            const float lx = fx - (float)x0, hx = 1.f - lx;
+            o[ox] = hy * (hx * r0[x0] + lx * r0[x1]) + ly * (hx * r1[x0] + lx * r1[x1]);
+        }
     }
 }
 
 hipError_t launch_bilinear(const float* x, float* y, int planes, int h, int w, int oh, int ow, hipStream_t s)
 {
-    const size_t total = (size_t)planes * oh * ow;
-    unsigned grid = (unsigned)((total + 255) / 256);
-    if (grid > 256u * 16u) grid = 256u * 16u;
-    if (grid == 0) return hipSuccess;
-    hipLaunchKernelGGL(bilinear_kernel, dim3(grid), dim3(256), 0, s, x, y, planes, h, w, oh, ow,
+    const size_t rows = (size_t)planes * oh;
+    if (rows == 0 || ow <= 0) return hipSuccess;
+    if (rows > 0xffffffffull) return hipErrorInvalidValue;
+    size_t grid = (rows + 3) / 4;
+    if (grid > 256u * 32u) grid = 256u * 32u;
+    hipLaunchKernelGGL(bilinear_kernel, dim3((unsigned)grid), dim3(256), 0, s, x, y, (unsigned)rows, h, w, oh, ow,
                        (float)h / (float)oh, (float)w / (float)ow);
     return hipGetLastError();
 }
