@@ -239,9 +239,14 @@ class GanStep:
     def d_step(self, lr_img: torch.Tensor, hr_img: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """Updates the discriminator; returns (d_loss, real_logits) -- the logits the generator step of the same iteration
         uses (computed BEFORE the update, as in the reference)."""
-        g = self.gen.g
-        with torch.no_grad():
-            fake = g(lr_img.to(torch.float32))                       # train mode: batch statistics, running stats move
+        if not self.gen.g.training:
+            raise RuntimeError("GanStep runs the generator in train mode (train.py:132): call generator.train()")
+        # train-mode forward without a graph (train.py:147-149): batch statistics, running stats move.  Through the step's
+        # own operators (device-made weight images) rather than generator(lr), which would re-upload and re-pack every
+        # weight on the host after each optimizer step
+        fake, S = self.gen.forward(lr_img)
+        self.gen._update_running_stats(S, fake.shape[0])
+        del S
         hr = hr_img.detach().to(torch.float32)
         n = hr.shape[0]
         self.opt_d.zero_grad()

@@ -189,8 +189,9 @@ class FlatAdamW(torch.optim.Optimizer):
                                               self.exp_avg_sq.data_ptr(), self.flat.numel(), float(g["lr"]),
                                               float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
                                               float(g["weight_decay"]), self.steps, _stream(self.flat)))
-        for p in self.params:               # in-place kernel update: tell torch the storage changed (weight re-upload)
-            p.data = p.data
+        # the kernel wrote the parameters behind torch's back: bump their version counters, which is what the Generator /
+        # Discriminator mirrors watch to re-fold and re-upload their weights before the next eval forward
+        torch.autograd.graph.increment_version(self.params)
 
     def state_dict(self) -> dict:
         g = {k: v for k, v in self.param_groups[0].items() if k != "params"}

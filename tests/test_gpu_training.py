@@ -271,7 +271,17 @@ def test_pretrain_step_updates_parameters_and_running_stats():
     losses = [loss0] + [float(step.step(lr, hr)) for _ in range(4)]
     print("pre-train losses over 5 steps on one batch:", losses)
     assert losses[-1] < losses[0]
-    # the eval forward picks the updated weights up (re-fold from the stepped parameters)
+    # the eval forward picks the updated weights up (re-fold from the stepped parameters and running statistics): it
+    # equals a fresh Generator loaded with the stepped state_dict, and differs from the un-stepped one
     with torch.no_grad():
         y = g.eval()(lr)
+    g2 = Generator()
+    g2.load_state_dict({k: v.detach().cpu().clone() for k, v in g.state_dict().items()})
+    g0 = Generator()
+    g0.load_state_dict(W.synthetic_state_dict(0))
+    with torch.no_grad():
+        y2 = g2.cuda().eval()(lr)
+        y0 = g0.cuda().eval()(lr)
     assert torch.isfinite(y).all()
+    assert max_rel(y.cpu().numpy(), y2.cpu().numpy()) <= 1e-6
+    assert max_rel(y.cpu().numpy(), y0.cpu().numpy()) >= 1e-3
