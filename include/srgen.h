@@ -325,7 +325,9 @@ SRGEN_API int srgen_ragan_loss(const float* real, const float* fake, size_t n_re
 /* Replaces: the weight side of F.conv2d in Discriminator.py:9,23,35,37 for weights that change every step.
  *   mode 0: forward pack of a (cout, cin, 3, 3) weight (cin * cout * 9 floats)
  *   mode 1: pack of its data-gradient conv (cout -> cin channels, flipped taps; same size)
- *   mode 2: stem pack (cin 3, cout 64; 1792 floats)      mode 3: tail pack (cout 1; 9 * cin floats) */
+ *   mode 2: stem pack (cin 3, cout 64; 1792 floats)      mode 3: tail pack (cout 1; 9 * cin floats)
+ *   mode 4: the four output-parity packs of a STRIDE-2 layer's data gradient, back to back (1 + 2 + 2 + 4 taps:
+ *           cin * cout * 9 floats), for srdisc_conv_dgrad2 */
 SRGEN_API int srdisc_pack(const float* w_oihw, int cin, int cout, int mode, float* out, void* stream);
 
 /* Replaces: Conv2d(3, 64, 3, padding=1) + LeakyReLU (Discriminator.py:23-24) on an NCHW image, NHWC (n, h, w, 64) out. */
@@ -333,18 +335,22 @@ SRGEN_API int srdisc_stem_nhwc(const float* x_nchw, const float* wpack, const fl
                                int w, float slope, void* stream);
 
 /* Replaces: DiscBlock / head.0 forward (Discriminator.py:8-11,35-36): out = lrelu(conv(in) + bias), stride 1 | 2 -- and,
- * with a mode-1 pack, mask != NULL and stride 1, the data gradient: out = conv(in) * (mask > 0 ? 1 : slope), where in is
- * dpre of the layer above (through srdisc_dilate2 first if that layer has stride 2), mask the saved activation below
+ * with a mode-1 pack, mask != NULL and stride 1, the data gradient of a STRIDE-1 layer: out = conv(in) * (mask > 0 ? 1 :
+ * slope), where in is dpre of that layer (a stride-2 layer: srdisc_conv_dgrad2), mask the saved activation below
  * (the shape of out), bias unused.  cin, cout: multiples of 64, cin / 64 a power of two <= 8. */
 SRGEN_API int srdisc_conv_nhwc(const float* in, const float* wpack, const float* bias, const float* mask, float* out,
                                int n, int h, int w, int cin, int cout, int stride, float slope, void* stream);
 
+/* Replaces: the data gradient of a stride-2 DiscBlock (Discriminator.py:25,27,29,31) + the LeakyReLU derivative of the
+ * layer below: out (n, h, w, cin) from dpre (n, oh, ow, cout), oh = (h - 1) / 2 + 1; one launch per output parity
+ * (y mod 2, x mod 2), each running only the 1, 2 or 4 taps that reach it.  wpack4: srdisc_pack mode 4; mask: the saved
+ * activation (n, h, w, cin). */
+SRGEN_API int srdisc_conv_dgrad2(const float* dpre, const float* wpack4, const float* mask, float* out, int n, int h, int w,
+                                 int cin, int cout, float slope, void* stream);
+
 /* Replaces: Conv2d(256, 1, 3, padding=1) (Discriminator.py:37): logits (n, 1, h, w). */
 SRGEN_API int srdisc_tail(const float* in, const float* wpack, const float* bias, float* logits, int n, int h, int w,
                           int cin, void* stream);
-
-/* First half of a stride-2 layer's data gradient: out (n, h, w, c) = d (n, oh, ow, c) at even (y, x), zero elsewhere. */
-SRGEN_API int srdisc_dilate2(const float* d, float* out, int n, int oh, int ow, int h, int w, int c, void* stream);
 
 /* Replaces: weight / bias gradient of a Cin -> Cout layer: dw (cout, cin, 3, 3) OIHW, dbias [cout] (NULL to skip);
  * in (n, h, w, cin), dpre (n, oh, ow, cout).  Fixed summation order. */

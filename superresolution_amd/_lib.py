@@ -106,7 +106,8 @@ def lib() -> ctypes.CDLL:
     L.srdisc_stem_nhwc.argtypes = [vp, vp, vp, vp, i, i, i, f, vp]
     L.srdisc_conv_nhwc.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, f, vp]
     L.srdisc_tail.argtypes = [vp, vp, vp, vp, i, i, i, i, vp]
-    L.srdisc_dilate2.argtypes = [vp, vp, i, i, i, i, i, i, vp]
+    L.srdisc_conv_dgrad2.argtypes = [vp, vp, vp, vp, i, i, i, i, i, f, vp]
+    L.srdisc_conv_dgrad2.restype = i
     L.srdisc_conv_wgrad_scratch_bytes.argtypes = [i, i, i, i, i, psz]
     L.srdisc_conv_wgrad.argtypes = [vp, vp, i, i, i, i, i, i, vp, vp, vp, sz, vp]
     L.srdisc_stem_wgrad_scratch_bytes.argtypes = [psz]
@@ -116,7 +117,7 @@ def lib() -> ctypes.CDLL:
     L.srgen_ragan_loss_grad.argtypes = [vp, vp, sz, sz, f, f, f, vp, vp, vp]
     L.srgen_clip_grad_norm_scratch_bytes.argtypes = [psz]
     L.srgen_clip_grad_norm.argtypes = [vp, sz, f, vp, vp, sz, vp]
-    for name in ("srdisc_pack", "srdisc_stem_nhwc", "srdisc_conv_nhwc", "srdisc_tail", "srdisc_dilate2",
+    for name in ("srdisc_pack", "srdisc_stem_nhwc", "srdisc_conv_nhwc", "srdisc_tail",
                  "srdisc_conv_wgrad_scratch_bytes", "srdisc_conv_wgrad", "srdisc_stem_wgrad_scratch_bytes", "srdisc_stem_wgrad",
                  "srdisc_stem_dgrad", "srdisc_tail_bwd", "srgen_ragan_loss_grad", "srgen_clip_grad_norm_scratch_bytes",
                  "srgen_clip_grad_norm"):

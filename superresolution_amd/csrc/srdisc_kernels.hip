@@ -132,7 +132,10 @@ struct ConvTile {
     int cb;
 };
 
-template <int STRIDE, int G>
+// PAR (stride-2 data gradient, one output parity class per launch; srdisc_train_kernels.hip): the conv runs over the
+// class grid OH x OW of the upper layer's dpre with the 1, 2 or 4 taps of a.taps (4-bit tap ids, real taps first, id 15 =
+// padding that reads zeros), and output pixel (oy, ox) of the class is pixel (2 oy + py, 2 ox + px) of the FH x FW image.
+template <int STRIDE, int G, bool PAR = false>
 __global__ __launch_bounds__(256, G == 4 ? 1 : 2) void disc_conv_kernel(DiscConvArgs a, int OH, int OW, int M,
                                                                         int lg_nst, int ntiles)
 {
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(256, G == 4 ? 1 : 2) void disc_conv_kernel(DiscConv
     const int l16 = lane & 15, kq = lane >> 4;
     const int ncb = a.Cout >> 6;
     const int nst = 1 << lg_nst;               // steps (of 4 chunks = 64 input channels) per tap
-    const int total = 9 * nst;
+    const int total = (PAR ? a.ntaps : 9) * nst;
     const float* zero = a.zeros + kq * 4;
 
     auto setup = [&](ConvTile<G>& T, int t) {
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(256, G == 4 ? 1 : 2) void disc_conv_kernel(DiscConv
                 const int iy = iy0 + k / 3, ix = ix0 + k % 3;
                 if (pv && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) m |= 1u << k;
             }
-            T.p[g] = p;
+            T.p[g] = !PAR ? p : pv ? (img * a.FH + 2 * oy + a.py) * a.FW + 2 * ox + a.px : -1;
             T.vmask[g] = m;
             T.base[g] = a.in + (((long long)img * a.H + iy0) * a.W + ix0) * a.Cin + kq * 4;
         }
@@ -170,7 +173,8 @@ __global__ __launch_bounds__(256, G == 4 ? 1 : 2) void disc_conv_kernel(DiscConv
 
     const float* cur[G];                        // the activation pointers (chunk 0) of the step being loaded
     auto set_step = [&](const ConvTile<G>& T, int st) {
-        const int tap = st >> lg_nst, c4 = st & (nst - 1);
+        const int c4 = st & (nst - 1);
+        const int tap = PAR ? (int)((a.taps >> (4 * (st >> lg_nst))) & 15u) : st >> lg_nst;      // 15: padding tap
         const int ky = tap / 3, kx = tap - 3 * ky;
         const int toff = (ky * a.W + kx) * a.Cin + c4 * 64;       // wave-uniform
 #pragma unroll
@@ -186,6 +190,7 @@ __global__ __launch_bounds__(256, G == 4 ? 1 : 2) void disc_conv_kernel(DiscConv
         for (int g = 0; g < G; ++g) xb[slot][g] = *reinterpret_cast<const f32x4*>(cur[g] + c * 16);
     };
     auto load_w = [&](int slot, const f32x4* wp, int st, int c) {
+        if (PAR && (st >> lg_nst) >= a.nreal) st &= nst - 1;     // a padding tap multiplies zeros: any real weights do
         const f32x4* w = wp + ((size_t)st * 4 + c) * 256;
 #pragma unroll
         for (int s = 0; s < 4; ++s) wb[slot][s] = w[s * 64];
@@ -238,7 +243,7 @@ __global__ __launch_bounds__(256, G == 4 ? 1 : 2) void disc_conv_kernel(DiscConv
     auto epilogue = [&](const ConvTile<G>& T) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            if (T.p[g] >= M) continue;
+            if (PAR ? T.p[g] < 0 : T.p[g] >= M) continue;
             float* o = a.out + (size_t)T.p[g] * a.Cout + T.cb * 64 + kq * 16;
             if (a.mask) {
                 // data-gradient use (srdisc_train_kernels.hip): no bias; times the LeakyReLU derivative at the
@@ -280,15 +285,19 @@ __global__ __launch_bounds__(256, G == 4 ? 1 : 2) void disc_conv_kernel(DiscConv
     clear();
     do_step(T, 0, T, 1);
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        do_step(T, 1, T, 2);
-        do_step(T, 2, T, 3);
-        for (int st = 3; st < total - 3; st += 3) {
-            do_step(T, st, T, st + 1);
-            do_step(T, st + 1, T, st + 2);
-            do_step(T, st + 2, T, st + 3);
+        if (PAR) {                               // total is 2 .. 32, not a multiple of three: plain loop
+            for (int st = 1; st < total - 1; ++st) do_step(T, st, T, st + 1);
+        } else {
+            do_step(T, 1, T, 2);
+            do_step(T, 2, T, 3);
+            for (int st = 3; st < total - 3; st += 3) {
+                do_step(T, st, T, st + 1);
+                do_step(T, st + 1, T, st + 2);
+                do_step(T, st + 2, T, st + 3);
+            }
+            do_step(T, total - 3, T, total - 2);
+            do_step(T, total - 2, T, total - 1);
         }
-        do_step(T, total - 3, T, total - 2);
-        do_step(T, total - 2, T, total - 1);
         const int tn = t + gridDim.x;
         ConvTile<G> N;
         setup(N, tn < ntiles ? tn : t);         // past the last tile: harmless re-loads of this one
@@ -397,17 +406,11 @@ hipError_t launch_disc_stem(const DiscStemArgs& a, hipStream_t s)
     return hipGetLastError();
 }
 
-hipError_t launch_disc_conv(const DiscConvArgs& a, hipStream_t s)
+static hipError_t launch_conv_grid(const DiscConvArgs& a, int OH, int OW, long long M, bool par, hipStream_t s)
 {
-    if (a.N <= 0) return hipSuccess;
     const int nst = a.Cin >> 6;                 // steps of 64 input channels per tap
-    if (a.Cin % 64 || a.Cin > kDiscZeroFloats || a.Cout % 64 || (nst & (nst - 1)) || !a.zeros ||
-        (a.stride != 1 && a.stride != 2) || a.H < 1 || a.W < 1)
-        return hipErrorInvalidValue;
     int lg = 0;
     while ((1 << lg) < nst) ++lg;
-    const int OH = (a.H - 1) / a.stride + 1, OW = (a.W - 1) / a.stride + 1;
-    const long long M = (long long)a.N * OH * OW;
     // 64 pixels per wave (16 accumulators) when that still gives every CU a workgroup, 32 otherwise
     // (small batches / the late layers)
     static const int wide_min = getenv("SRDISC_WIDE_MIN") ? atoi(getenv("SRDISC_WIDE_MIN")) : 256;
@@ -432,7 +435,11 @@ hipError_t launch_disc_conv(const DiscConvArgs& a, hipStream_t s)
     const long long resident = (long long)cus * per_cu;
     const dim3 grid((unsigned)(blocks < resident ? blocks : resident)), block(256);
     const int ntiles = (int)blocks;
-    if (a.stride == 1 && wide)
+    if (par && wide)
+        hipLaunchKernelGGL((disc_conv_kernel<1, 4, true>), grid, block, lds_pad, s, a, OH, OW, (int)M, lg, ntiles);
+    else if (par)
+        hipLaunchKernelGGL((disc_conv_kernel<1, 2, true>), grid, block, lds_pad, s, a, OH, OW, (int)M, lg, ntiles);
+    else if (a.stride == 1 && wide)
         hipLaunchKernelGGL((disc_conv_kernel<1, 4>), grid, block, lds_pad, s, a, OH, OW, (int)M, lg, ntiles);
     else if (a.stride == 1)
         hipLaunchKernelGGL((disc_conv_kernel<1, 2>), grid, block, lds_pad, s, a, OH, OW, (int)M, lg, ntiles);
@@ -441,6 +448,52 @@ hipError_t launch_disc_conv(const DiscConvArgs& a, hipStream_t s)
     else
         hipLaunchKernelGGL((disc_conv_kernel<2, 2>), grid, block, lds_pad, s, a, OH, OW, (int)M, lg, ntiles);
     return hipGetLastError();
+}
+
+static bool conv_args_ok(const DiscConvArgs& a)
+{
+    const int nst = a.Cin >> 6;
+    return !(a.Cin % 64 || a.Cin > kDiscZeroFloats || a.Cout % 64 || (nst & (nst - 1)) || !a.zeros || a.H < 1 || a.W < 1);
+}
+
+hipError_t launch_disc_conv(const DiscConvArgs& a, hipStream_t s)
+{
+    if (a.N <= 0) return hipSuccess;
+    if (!conv_args_ok(a) || (a.stride != 1 && a.stride != 2)) return hipErrorInvalidValue;
+    const int OH = (a.H - 1) / a.stride + 1, OW = (a.W - 1) / a.stride + 1;
+    return launch_conv_grid(a, OH, OW, (long long)a.N * OH * OW, false, s);
+}
+
+// Data gradient of a stride-2 layer: a0.in = dpre (N, H, W, Cin) of that layer (H x W its OUTPUT grid), a0.out / a0.mask
+// (N, fh, fw, Cout) its input grid; wpack4 = the four class packs back to back (disc_pack mode 4 .. 7: 1, 2, 2, 4 taps).
+hipError_t launch_disc_dgrad2(const DiscConvArgs& a0, const float* wpack4, int fh, int fw, hipStream_t s)
+{
+    if (a0.N <= 0) return hipSuccess;
+    if (!conv_args_ok(a0) || !a0.mask || (fh - 1) / 2 + 1 != a0.H || (fw - 1) / 2 + 1 != a0.W) return hipErrorInvalidValue;
+    const int nst = a0.Cin >> 6;
+    size_t woff = 0;
+    for (int c = 0; c < 4; ++c) {
+        const int py = c >> 1, px = c & 1;
+        const int ntaps = (py + 1) * (px + 1);
+        DiscConvArgs a = a0;
+        a.stride = 1;
+        a.wpack = wpack4 + woff;
+        woff += (size_t)ntaps * a0.Cin * a0.Cout;
+        const int CH = (fh - py + 1) / 2, CW = (fw - px + 1) / 2;           // rows / columns of that parity in the image
+        if (CH <= 0 || CW <= 0) continue;
+        unsigned long long taps = 0;
+        int k = 0;
+        for (int ky = 1; ky <= 1 + py; ++ky)
+            for (int kx = 1; kx <= 1 + px; ++kx) taps |= (unsigned long long)(ky * 3 + kx) << (4 * k++);
+        a.nreal = ntaps;
+        while (k * nst < 2) taps |= 15ull << (4 * k++);                     // the pipeline wants two steps
+        a.taps = taps;
+        a.ntaps = k;
+        a.py = py; a.px = px; a.FH = fh; a.FW = fw;
+        hipError_t e = launch_conv_grid(a, CH, CW, (long long)a.N * CH * CW, true, s);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 hipError_t launch_disc_tail(const DiscTailArgs& a, hipStream_t s)

@@ -43,8 +43,9 @@ extern "C" {
 int srdisc_pack(const float* w_oihw, int cin, int cout, int mode, float* out, void* stream)
 {
     if (!w_oihw || !out) return fail(SRGEN_E_INVALID, "NULL argument");
-    if (mode < 0 || mode > 3) return fail(SRGEN_E_INVALID, "mode %d: 0 forward, 1 data gradient, 2 stem, 3 tail", mode);
-    if (mode <= 1) { if (int rc = check_channels(mode ? cout : cin, mode ? cin : cout)) return rc; }
+    if (mode < 0 || mode > 4)
+        return fail(SRGEN_E_INVALID, "mode %d: 0 forward, 1 data gradient, 2 stem, 3 tail, 4 stride-2 data gradient", mode);
+    if (mode <= 1 || mode == 4) { if (int rc = check_channels(mode ? cout : cin, mode ? cin : cout)) return rc; }
     else if (mode == 2 && (cin != 3 || cout != 64)) return fail(SRGEN_E_UNSUPPORTED, "stem pack is 3 -> 64");
     else if (mode == 3 && (cin % 4 || cout != 1)) return fail(SRGEN_E_UNSUPPORTED, "tail pack is cin -> 1, cin %% 4 == 0");
     HIP_TRY(launch_disc_pack(w_oihw, out, cin, cout, mode, (hipStream_t)stream));
@@ -79,6 +80,23 @@ int srdisc_conv_nhwc(const float* in, const float* wpack, const float* bias, con
     return SRGEN_OK;
 }
 
+int srdisc_conv_dgrad2(const float* dpre, const float* wpack4, const float* mask, float* out, int n, int h, int w, int cin, int cout,
+                       float slope, void* stream)
+{
+    if (!dpre || !wpack4 || !mask || !out) return fail(SRGEN_E_INVALID, "NULL argument");
+    if (int rc = check_img(n, h, w)) return rc;
+    if (int rc = check_channels(cout, cin)) return rc;              // the gradient conv runs cout -> cin channels
+    if (!aligned16(dpre) || !aligned16(wpack4) || !aligned16(mask) || !aligned16(out))
+        return fail(SRGEN_E_INVALID, "operands must be 16-byte aligned");
+    const float* zeros = nullptr;
+    if (int rc = train_zero_page(&zeros)) return rc;
+    const int oh = (h - 1) / 2 + 1, ow = (w - 1) / 2 + 1;
+    DiscConvArgs a{dpre, out, wpack4, nullptr, n, oh, ow, cout, cin, 1, slope, zeros};
+    a.mask = mask;
+    HIP_TRY(launch_disc_dgrad2(a, wpack4, h, w, (hipStream_t)stream));
+    return SRGEN_OK;
+}
+
 int srdisc_tail(const float* in, const float* wpack, const float* bias, float* logits, int n, int h, int w, int cin, void* stream)
 {
     if (!in || !wpack || !bias || !logits) return fail(SRGEN_E_INVALID, "NULL argument");
@@ -86,16 +104,6 @@ int srdisc_tail(const float* in, const float* wpack, const float* bias, float* l
     if (cin % 4 || !aligned16(in) || !aligned16(wpack)) return fail(SRGEN_E_INVALID, "cin %% 4 and 16-byte alignment required");
     DiscTailArgs a{in, logits, wpack, bias, n, h, w, cin};
     HIP_TRY(launch_disc_tail(a, (hipStream_t)stream));
-    return SRGEN_OK;
-}
-
-int srdisc_dilate2(const float* d, float* out, int n, int oh, int ow, int h, int w, int c, void* stream)
-{
-    if (!d || !out) return fail(SRGEN_E_INVALID, "NULL argument");
-    if (int rc = check_img(n, h, w)) return rc;
-    if (c % 4 || (h - 1) / 2 + 1 != oh || (w - 1) / 2 + 1 != ow || !aligned16(d) || !aligned16(out))
-        return fail(SRGEN_E_INVALID, "dilate2: (%d, %d) is not the stride-2 output of (%d, %d), or c %% 4, or alignment", oh, ow, h, w);
-    HIP_TRY(launch_dilate2(d, out, n, oh, ow, h, w, c, (hipStream_t)stream));
     return SRGEN_OK;
 }
 

@@ -7,8 +7,8 @@
 // sign of pre_i -- so no pre-activation is kept.  Per layer i:
 //   data gradient    dout_{i-1} = conv_transpose(dpre_i, W_i): the FORWARD kernel (srdisc_kernels.hip) on a
 //                    device-made pack of the flipped, transposed weights (disc_pack_kernel mode 1), its epilogue
-//                    multiplying by lrelu'(out_{i-1}); a stride-2 layer first spreads dpre_i over the input grid
-//                    (dilate2_kernel: value at (2oy, 2ox), zero elsewhere), which turns it into a stride-1 conv;
+//                    multiplying by lrelu'(out_{i-1}); a stride-2 layer runs one launch per output parity (y mod 2,
+//                    x mod 2) with the 1, 2 or 4 taps that reach that parity (disc_pack_par_kernel, PAR kernel variant);
 //   weight gradient  disc_wgrad_kernel: GEMM M = co, N = ci, K = output pixels per tap on v_mfma_f32_16x16x4_f32.
 // Activations are NHWC fp32, weights and their gradients OIHW fp32 (the torch parameters themselves).
 #include "srgen_internal.h"
@@ -44,6 +44,31 @@ __global__ __launch_bounds__(256) void disc_pack_kernel(const float* __restrict_
     out[idx] = mode ? w[((size_t)ci * cin + co) * 9 + (8 - tap)] : w[((size_t)co * cin + ci) * 9 + tap];
 }
 
+// Packs of a stride-2 layer's data gradient, one per output parity class (py, px) (disc_conv_kernel<.., PAR>): input
+// pixel y = 2a + py receives dpre[a + dy] * w[ky] with ky = py + 1 - 2 dy, dy in {0} (py = 0) or {0, 1} (py = 1), and the
+// same along x: 1, 2, 2, 4 taps instead of the nine a zero-stuffed stride-1 conv would run.  Tap k of the class =
+// (ky', kx') = (1 + dy, 1 + dx), ky' outer; layout [cout'/64][k][cin'/16][s 4][lane 64] with cin' = cout, cout' = cin.
+__global__ __launch_bounds__(256) void disc_pack_par_kernel(const float* __restrict__ w, float* __restrict__ out, int cin, int cout,
+                                                            int py, int px, size_t total)
+{
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int nch = cout / 16, ntaps = (py + 1) * (px + 1);
+    const int j = (int)(idx & 3);
+    size_t unit = idx >> 2;
+    const int lane = (int)(unit & 63); unit >>= 6;
+    const int s = (int)(unit & 3); unit >>= 2;
+    const int ch = (int)(unit % nch); unit /= nch;
+    const int k = (int)(unit % ntaps);
+    const int cb = (int)(unit / ntaps);
+    const int m = lane & 15, kq = lane >> 4;
+    const int cop = 64 * cb + 16 * (m >> 2) + 4 * s + (m & 3);          // packed output channel = the layer's ci
+    const int cip = 16 * ch + 4 * kq + j;                                // packed input channel = the layer's co
+    const int dy = k / (px + 1), dx = k % (px + 1);
+    const int ky = py + 1 - 2 * dy, kx = px + 1 - 2 * dx;
+    out[idx] = w[((size_t)cip * cin + cop) * 9 + ky * 3 + kx];
+}
+
 // stem pack [j 7][s 4][lane 64] (pack_disc_stem) and tail pack [tap 9][cin] (pack_disc_tail)
 __global__ __launch_bounds__(256) void disc_pack_small_kernel(const float* __restrict__ w, float* __restrict__ out, int cin, int tail)
 {
@@ -58,22 +83,6 @@ __global__ __launch_bounds__(256) void disc_pack_small_kernel(const float* __res
     const int co = 16 * (m >> 2) + 4 * s + (m & 3);
     const int k = 4 * j + kq;
     out[idx] = k < 27 ? w[((size_t)co * 3 + k % 3) * 9 + k / 3] : 0.f;
-}
-
-// ---- stride-2 data gradient, step 1: spread dpre (n, oh, ow, c) over the layer's input grid (n, h, w, c) ---------
-__global__ __launch_bounds__(256) void dilate2_kernel(const float* __restrict__ d, float* __restrict__ out, int oh, int ow, int h,
-                                                      int w, int c4, size_t total4)
-{
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
-        const int c = (int)(i % c4);
-        size_t p = i / c4;
-        const int x = (int)(p % w); p /= w;
-        const int y = (int)(p % h);
-        const size_t img = p / h;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (!((x | y) & 1)) v = *(const f32x4*)(d + (((img * oh + (y >> 1)) * ow + (x >> 1)) * c4 + c) * 4);
-        *(f32x4*)(out + i * 4) = v;
-    }
 }
 
 // ---- weight gradient of a Cin -> Cout layer (both multiples of 64), stride 1 or 2 -------------------------------------
@@ -467,17 +476,19 @@ hipError_t launch_disc_pack(const float* w, float* out, int cin, int cout, int m
         return hipGetLastError();
     }
     if (cin % 64 || cout % 64) return hipErrorInvalidValue;
+    if (mode == 4) {                                                     // the four parity-class packs back to back
+        size_t off = 0;
+        for (int c = 0; c < 4; ++c) {
+            const int py = c >> 1, px = c & 1;
+            const size_t total = (size_t)(py + 1) * (px + 1) * cin * cout;
+            hipLaunchKernelGGL(disc_pack_par_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, out + off, cin, cout,
+                               py, px, total);
+            off += total;
+        }
+        return hipGetLastError();
+    }
     const size_t total = (size_t)cin * cout * 9;
     hipLaunchKernelGGL(disc_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, out, cin, cout, mode, total);
-    return hipGetLastError();
-}
-
-hipError_t launch_dilate2(const float* d, float* out, int n, int oh, int ow, int h, int w, int c, hipStream_t s)
-{
-    if (c % 4 || (h - 1) / 2 + 1 != oh || (w - 1) / 2 + 1 != ow) return hipErrorInvalidValue;
-    const size_t total4 = (size_t)n * h * w * (c / 4);
-    const size_t want = (total4 + 255) / 256;
-    hipLaunchKernelGGL(dilate2_kernel, dim3((unsigned)(want < 16384 ? want : 16384)), dim3(256), 0, s, d, out, oh, ow, h, w, c / 4, total4);
     return hipGetLastError();
 }
 

@@ -132,6 +132,9 @@ struct DiscConvArgs {          // conv Cin -> Cout (Cin % 16 == 0, Cout % 64 == 
     float slope;               // LeakyReLU slope
     const float* zeros;        // kDiscZeroFloats zeros in device memory: what out-of-image taps read
     const float* mask = nullptr;   // data-gradient use: (N,OH,OW,Cout) saved activation; out = acc * (mask > 0 ? 1 : slope)
+    // stride-2 data gradient, one output parity class (disc_conv_kernel<.., PAR = true>)
+    unsigned long long taps = 0;   // 4-bit tap ids (ky*3 + kx), real taps first, 15 = padding
+    int ntaps = 0, nreal = 0, py = 0, px = 0, FH = 0, FW = 0;
 };
 constexpr int kDiscZeroFloats = 512;
 struct DiscTailArgs {          // conv Cin -> 1, stride 1, pad 1, no activation
@@ -143,6 +146,7 @@ struct DiscTailArgs {          // conv Cin -> 1, stride 1, pad 1, no activation
 };
 hipError_t launch_disc_stem(const DiscStemArgs& a, hipStream_t s);
 hipError_t launch_disc_conv(const DiscConvArgs& a, hipStream_t s);
+hipError_t launch_disc_dgrad2(const DiscConvArgs& a0, const float* wpack4, int fh, int fw, hipStream_t s);
 hipError_t launch_disc_tail(const DiscTailArgs& a, hipStream_t s);
 hipError_t launch_ragan_loss(const float* real, const float* fake, size_t n_real, size_t n_fake,
                              float real_label, float fake_label, float* out2, hipStream_t s);
@@ -150,7 +154,6 @@ hipError_t launch_ragan_loss(const float* real, const float* fake, size_t n_real
 // ---- GAN-phase backward operators (srdisc_train_kernels.hip) ---------------------------------------------------------
 // packs from live OIHW weights on the device: mode 0 forward conv, 1 data-gradient conv, 2 stem, 3 tail
 hipError_t launch_disc_pack(const float* w, float* out, int cin, int cout, int mode, hipStream_t s);
-hipError_t launch_dilate2(const float* d, float* out, int n, int oh, int ow, int h, int w, int c, hipStream_t s);
 size_t disc_wgrad_scratch_bytes(int n, int oh, int cin, int cout);
 hipError_t launch_disc_wgrad(const float* in, const float* dpre, int n, int h, int w, int cin, int cout, int stride, float* dw,
                              float* dbias, void* scratch, hipStream_t s);

@@ -88,7 +88,7 @@ class DiscriminatorGrad:
     def _pack(self, conv: torch.nn.Conv2d, mode: int) -> torch.Tensor:
         w = conv.weight.detach().contiguous()
         cout, cin = w.shape[0], w.shape[1]
-        numel = {0: w.numel(), 1: w.numel(), 2: 7 * 4 * 64, 3: 9 * cin}[mode]
+        numel = {0: w.numel(), 1: w.numel(), 2: 7 * 4 * 64, 3: 9 * cin, 4: w.numel()}[mode]
         out = torch.empty(numel, dtype=torch.float32, device=w.device)
         with torch.cuda.device(w.device):
             _lib.check(_lib.lib().srdisc_pack(w.data_ptr(), cin, cout, mode, out.data_ptr(), _stream(w)))
@@ -174,13 +174,13 @@ class DiscriminatorGrad:
                     put(conv, dw, db)
                 if i == 1 and not want_wgrad and not want_dimg:
                     break
-                src = dpre
-                if st == 2:
-                    src = torch.empty((n, ih, iw, cout), dtype=torch.float32, device=self.dev)
-                    _lib.check(L.srdisc_dilate2(dpre.data_ptr(), src.data_ptr(), n, oh, ow, ih, iw, cout, s))
                 nxt = torch.empty((n, ih, iw, cin), dtype=torch.float32, device=self.dev)
-                _lib.check(L.srdisc_conv_nhwc(src.data_ptr(), self._pack(conv, 1).data_ptr(), None, acts[i - 1].data_ptr(),
-                                              nxt.data_ptr(), n, ih, iw, cout, cin, 1, SLOPE, s))
+                if st == 2:                        # one launch per output parity: only the taps that reach it
+                    _lib.check(L.srdisc_conv_dgrad2(dpre.data_ptr(), self._pack(conv, 4).data_ptr(), acts[i - 1].data_ptr(),
+                                                    nxt.data_ptr(), n, ih, iw, cin, cout, SLOPE, s))
+                else:
+                    _lib.check(L.srdisc_conv_nhwc(dpre.data_ptr(), self._pack(conv, 1).data_ptr(), None, acts[i - 1].data_ptr(),
+                                                  nxt.data_ptr(), n, ih, iw, cout, cin, 1, SLOPE, s))
                 dpre = nxt
             c0 = self.convs[0]
             h0, w0 = sizes[0]
