@@ -182,7 +182,7 @@ def training_leg(args, dev, rank, n_ranks, use_dist):
                        "collective": "one all-reduce of the flat gradient buffer per optimizer step (12.86 MB generator, "
                                      "23.5 MB discriminator)"},
             "loss_last": float(loss),
-            "roofline": {"bound": "mfma", "kernel": "conv3x3_wgrad_wino_kernel + sum + final (38 launches per generator backward)",
+            "roofline": {"bound": "mfma", "kernel": "conv3x3_wgrad_wino_lds_kernel + sum + final (38 launches per generator backward)",
                          "achieved": round(flop / (wg_ms * 1e-3) / 1e12, 2), "peak": 157.3, "unit": "TFLOP/s",
                          "frac": round(flop / (wg_ms * 1e-3) / 1e12 / 157.3, 4), "traffic": None,
                          "ms_per_launch": round(wg_ms, 4), "flop_per_launch_executed": flop, "flop_per_launch_algorithmic": flop_alg,

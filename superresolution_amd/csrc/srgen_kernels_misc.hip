@@ -359,33 +359,38 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
     }
 }
 
+// grid 8: block b owns channels [12b, 12b + 12): 24 sums x 32 threads, each adding every 32nd partial (fixed order)
 __global__ __launch_bounds__(768) void bn_final_kernel(const double* partial, int nb, double npix,
                                                        const float* gamma, const float* beta, float eps,
                                                        float* scale_shift, float* batch_stats)
 {
-    __shared__ double part[4][192];
-    __shared__ double tot[192];
-    {   // 4 threads per column, fixed order
-        const int col = threadIdx.x % 192, q = threadIdx.x / 192;
+    __shared__ double part[32][24];
+    __shared__ double tot[24];
+    {
+        const int s = threadIdx.x % 24, q = threadIdx.x / 24;
+        const int col = (s / 12) * 96 + blockIdx.x * 12 + s % 12;
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;           // four loads in flight, fixed order
         int b = q;
-        for (; b + 12 < nb; b += 16) {
+        for (; b + 96 < nb; b += 128) {
             a0 += partial[(size_t)b * 192 + col];
-            a1 += partial[(size_t)(b + 4) * 192 + col];
-            a2 += partial[(size_t)(b + 8) * 192 + col];
-            a3 += partial[(size_t)(b + 12) * 192 + col];
+            a1 += partial[(size_t)(b + 32) * 192 + col];
+            a2 += partial[(size_t)(b + 64) * 192 + col];
+            a3 += partial[(size_t)(b + 96) * 192 + col];
         }
-        for (; b < nb; b += 4) a0 += partial[(size_t)b * 192 + col];
-        part[q][col] = (a0 + a1) + (a2 + a3);
+        for (; b < nb; b += 32) a0 += partial[(size_t)b * 192 + col];
+        part[q][s] = (a0 + a1) + (a2 + a3);
     }
     __syncthreads();
-    if (threadIdx.x < 192) tot[threadIdx.x] = (part[0][threadIdx.x] + part[1][threadIdx.x]) +
-                                              (part[2][threadIdx.x] + part[3][threadIdx.x]);
+    if (threadIdx.x < 24) {
+        double a = 0.0;
+        for (int q = 0; q < 32; ++q) a += part[q][threadIdx.x];
+        tot[threadIdx.x] = a;
+    }
     __syncthreads();
-    if (threadIdx.x < 96) {
-        const int c = threadIdx.x;
-        const double mean = tot[c] / npix;
-        double var = tot[96 + c] / npix - mean * mean;          // biased (what the normalisation uses)
+    if (threadIdx.x < 12) {
+        const int c = blockIdx.x * 12 + threadIdx.x;
+        const double mean = tot[threadIdx.x] / npix;
+        double var = tot[12 + threadIdx.x] / npix - mean * mean;   // biased (what the normalisation uses)
         var = var > 0.0 ? var : 0.0;
         const double sc = (double)gamma[c] / sqrt(var + (double)eps);
         scale_shift[c] = (float)sc;
@@ -454,7 +459,7 @@ hipError_t launch_bn_train(float* t, size_t npix, const float* gamma, const floa
     float* ss = reinterpret_cast<float*>(partial + (size_t)kBnBlocks * 192);
     const int nb = npix < (size_t)kBnBlocks * 10 ? (int)((npix + 9) / 10) : kBnBlocks;
     hipLaunchKernelGGL(bn_stats_kernel, dim3(nb), dim3(256), 0, s, t, npix, partial);
-    hipLaunchKernelGGL(bn_final_kernel, dim3(1), dim3(768), 0, s, partial, nb, (double)npix, gamma, beta, 1e-5f, ss,
+    hipLaunchKernelGGL(bn_final_kernel, dim3(8), dim3(768), 0, s, partial, nb, (double)npix, gamma, beta, 1e-5f, ss,
                        batch_stats);
     const size_t n4 = npix * 24;
     const size_t want = (n4 + 255) / 256;

@@ -74,8 +74,19 @@ def conv3x3(x: torch.Tensor, wpack: torch.Tensor, bias: Optional[torch.Tensor] =
     return out
 
 
-def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, ws: Workspace) -> Tuple[torch.Tensor, torch.Tensor]:
-    """(dw (96, 96, 3, 3), dbias (96,)) of ``F.conv2d(x, w, b, padding=1)`` given ``dy``; NHWC fp32 operands."""
+def _out(t: Optional[torch.Tensor], shape, dev) -> torch.Tensor:
+    """``t`` (a contiguous fp32 gradient view to write into, e.g. ``p.grad``) or a fresh tensor of ``shape``."""
+    if t is None:
+        return torch.empty(shape, dtype=torch.float32, device=dev)
+    if not t.is_contiguous() or t.dtype != torch.float32 or t.numel() != int(torch.Size(shape).numel()):
+        raise RuntimeError(f"gradient output must be a contiguous fp32 tensor of {tuple(shape)}, got {tuple(t.shape)} {t.dtype}")
+    return t
+
+
+def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, ws: Workspace, dw: Optional[torch.Tensor] = None,
+                  db: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(dw (96, 96, 3, 3), dbias (96,)) of ``F.conv2d(x, w, b, padding=1)`` given ``dy``; NHWC fp32 operands.  ``dw`` /
+    ``db``: write into these (``p.grad`` views) instead of fresh tensors."""
     _chk_nhwc("x", x)
     _chk_nhwc("dy", dy)
     n, hw = x.shape[0], x.shape[1]
@@ -83,8 +94,8 @@ def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, ws: Workspace) -> Tuple[tor
     need = ctypes.c_size_t()
     _lib.check(L.srgen_conv3x3_wgrad_scratch_bytes(n, hw, ctypes.byref(need)))
     scratch = ws.get("wgrad", need.value)
-    dw = torch.empty((96, 96, 3, 3), dtype=torch.float32, device=x.device)
-    db = torch.empty(96, dtype=torch.float32, device=x.device)
+    dw = _out(dw, (96, 96, 3, 3), x.device)
+    db = _out(db, (96,), x.device)
     with torch.cuda.device(x.device):
         _lib.check(L.srgen_conv3x3_wgrad(x.data_ptr(), dy.data_ptr(), n, hw, dw.data_ptr(), db.data_ptr(), scratch.data_ptr(),
                                          scratch.numel(), _stream(x)))
@@ -112,14 +123,16 @@ def bn_train_fwd(c: torch.Tensor, gamma, beta, ws: Workspace, slope=None, res=No
     return out, stats
 
 
-def bn_train_bwd(c, dout, stats, gamma, beta, ws: Workspace, slope=None, dout_scale: float = 1.0):
-    """(dc, dgamma, dbeta, dslope | None) of ``PReLU(bn(c))`` in train mode given ``dout * dout_scale``."""
+def bn_train_bwd(c, dout, stats, gamma, beta, ws: Workspace, slope=None, dout_scale: float = 1.0, dgamma=None, dbeta=None,
+                 dslope=None):
+    """(dc, dgamma, dbeta, dslope | None) of ``PReLU(bn(c))`` in train mode given ``dout * dout_scale``.  ``dgamma`` /
+    ``dbeta`` / ``dslope``: write into these (``p.grad`` views) instead of fresh tensors."""
     _chk_nhwc("c", c)
     _chk_nhwc("dout", dout)
     dev = c.device
     dc = torch.empty_like(c)
-    dgamma, dbeta = torch.empty(96, dtype=torch.float32, device=dev), torch.empty(96, dtype=torch.float32, device=dev)
-    dslope = torch.empty(96, dtype=torch.float32, device=dev) if slope is not None else None
+    dgamma, dbeta = _out(dgamma, (96,), dev), _out(dbeta, (96,), dev)
+    dslope = _out(dslope, (96,), dev) if slope is not None else None
     scratch = _bn_scratch(ws)
     with torch.cuda.device(dev):
         _lib.check(_lib.lib().srgen_bn_train_bwd(c.data_ptr(), dout.data_ptr(), stats.data_ptr(), gamma.data_ptr(),
@@ -219,19 +232,23 @@ def resblock_forward(x: torch.Tensor, block: torch.nn.Module, ws: Workspace):
     return out, {"x": x, "c1": c1, "t": t, "c2": c2, "st1": st1, "st2": st2}
 
 
-def resblock_backward(dout: torch.Tensor, saved: dict, block: torch.nn.Module, ws: Workspace):
-    """(dx, {state_dict key -> gradient}) given ``dout`` = gradient of the block output."""
+def resblock_backward(dout: torch.Tensor, saved: dict, block: torch.nn.Module, ws: Workspace, into: Optional[dict] = None):
+    """(dx, {state_dict key -> gradient}) given ``dout`` = gradient of the block output.  ``into``: {key -> tensor} the
+    gradients are written to directly (the ``p.grad`` views of the step) instead of fresh tensors."""
     seq = block.block
     g: Dict[str, torch.Tensor] = {}
+    d = (lambda k: into[k]) if into is not None else (lambda k: None)
     # out = x + 0.1 * bn2(c2)
     dc2, g["block.4.weight"], g["block.4.bias"], _ = bn_train_bwd(saved["c2"], dout, saved["st2"], seq[4].weight.detach(),
-                                                                   seq[4].bias.detach(), ws, dout_scale=0.1)
-    g["block.3.weight"], g["block.3.bias"] = conv3x3_wgrad(saved["t"], dc2, ws)
+                                                                   seq[4].bias.detach(), ws, dout_scale=0.1,
+                                                                   dgamma=d("block.4.weight"), dbeta=d("block.4.bias"))
+    g["block.3.weight"], g["block.3.bias"] = conv3x3_wgrad(saved["t"], dc2, ws, d("block.3.weight"), d("block.3.bias"))
     dt = conv3x3(dc2, wino_pack(seq[3].weight, mode=1))
     # t = PReLU(bn1(c1))
     dc1, g["block.1.weight"], g["block.1.bias"], g["block.2.weight"] = bn_train_bwd(
-        saved["c1"], dt, saved["st1"], seq[1].weight.detach(), seq[1].bias.detach(), ws, slope=seq[2].weight.detach())
-    g["block.0.weight"], g["block.0.bias"] = conv3x3_wgrad(saved["x"], dc1, ws)
+        saved["c1"], dt, saved["st1"], seq[1].weight.detach(), seq[1].bias.detach(), ws, slope=seq[2].weight.detach(),
+        dgamma=d("block.1.weight"), dbeta=d("block.1.bias"), dslope=d("block.2.weight"))
+    g["block.0.weight"], g["block.0.bias"] = conv3x3_wgrad(saved["x"], dc1, ws, d("block.0.weight"), d("block.0.bias"))
     dx = conv3x3(dc1, wino_pack(seq[0].weight, mode=1), res=dout)          # + the identity branch
     return dx, g
 
@@ -325,7 +342,7 @@ def chan_attn_forward(x: torch.Tensor, ca: torch.nn.Module):
     return y, {"x": x, "pool": pool, "scale": scale}
 
 
-def chan_attn_backward(dy: torch.Tensor, saved: dict, ca: torch.nn.Module, ws: Workspace):
+def chan_attn_backward(dy: torch.Tensor, saved: dict, ca: torch.nn.Module, ws: Workspace, into: Optional[dict] = None):
     x = saved["x"]
     n, dev = x.shape[0], x.device
     L = _lib.lib()
@@ -334,10 +351,9 @@ def chan_attn_backward(dy: torch.Tensor, saved: dict, ca: torch.nn.Module, ws: W
     scratch = ws.get("ca", need.value)
     fc = ca.fc
     dx = torch.empty_like(x)
-    g = {"fc.0.weight": torch.empty((12, 96, 1, 1), dtype=torch.float32, device=dev),
-         "fc.0.bias": torch.empty(12, dtype=torch.float32, device=dev),
-         "fc.2.weight": torch.empty((96, 12, 1, 1), dtype=torch.float32, device=dev),
-         "fc.2.bias": torch.empty(96, dtype=torch.float32, device=dev)}
+    d = (lambda k: into[k]) if into is not None else (lambda k: None)
+    g = {"fc.0.weight": _out(d("fc.0.weight"), (12, 96, 1, 1), dev), "fc.0.bias": _out(d("fc.0.bias"), (12,), dev),
+         "fc.2.weight": _out(d("fc.2.weight"), (96, 12, 1, 1), dev), "fc.2.bias": _out(d("fc.2.bias"), (96,), dev)}
     with torch.cuda.device(dev):
         _lib.check(L.srgen_chan_attn_bwd(x.data_ptr(), dy.data_ptr(), saved["pool"].data_ptr(), saved["scale"].data_ptr(), n,
                                          fc[0].weight.data_ptr(), fc[0].bias.data_ptr(), fc[2].weight.data_ptr(),
@@ -422,9 +438,7 @@ class PretrainStep:
         # output[0..1]: conv3x3 at 128 x 128 + scalar PReLU (Generator.py:69-70)
         dv_pre, ds = prelu_scalar_bwd(S["v_pre"], dv, g.output[1].weight.detach(), ws)
         put("output.1.weight", ds)
-        dw, db = conv3x3_wgrad(S["u"], dv_pre, ws)
-        put("output.0.weight", dw)
-        put("output.0.bias", db)
+        conv3x3_wgrad(S["u"], dv_pre, ws, P["output.0.weight"].grad, P["output.0.bias"].grad)
         du = conv3x3(dv_pre, wino_pack(g.output[0].weight, mode=1))
         # upsample: conv 96 -> 384, PixelShuffle(2), scalar PReLU (Generator.py:4-12)
         up = g.upsample
@@ -441,22 +455,18 @@ class PretrainStep:
             gb[:, b].copy_(db)
             dm = conv3x3(pl, wino_pack(up.conv.weight, mode=1, block=b), res=dm)
         # mid conv + BatchNorm, long skip x1 + x3 (Generator.py:61-64,78)
-        dc, dg_, db_, _ = bn_train_bwd(S["mid_c"], dm, S["mid_st"], g.mid[1].weight.detach(), g.mid[1].bias.detach(), ws)
-        put("mid.1.weight", dg_)
-        put("mid.1.bias", db_)
-        dw, db = conv3x3_wgrad(S["mid_in"], dc, ws)
-        put("mid.0.weight", dw)
-        put("mid.0.bias", db)
+        dc, _, _, _ = bn_train_bwd(S["mid_c"], dm, S["mid_st"], g.mid[1].weight.detach(), g.mid[1].bias.detach(), ws,
+                                   dgamma=P["mid.1.weight"].grad, dbeta=P["mid.1.bias"].grad)
+        conv3x3_wgrad(S["mid_in"], dc, ws, P["mid.0.weight"].grad, P["mid.0.bias"].grad)
         dcur = conv3x3(dc, wino_pack(g.mid[0].weight, mode=1))
         # trunk, last module first (Generator.py:55-59)
         for idx in range(len(g.blocks) - 1, -1, -1):
             m, saved = g.blocks[idx], S["blocks"][idx]
-            if hasattr(m, "block"):
-                dcur, grads = resblock_backward(dcur, saved, m, ws)
+            into = {k[len(f"blocks.{idx}."):]: p.grad for k, p in P.items() if k.startswith(f"blocks.{idx}.")}
+            if hasattr(m, "block"):                       # gradients are written straight into the p.grad views
+                dcur, _ = resblock_backward(dcur, saved, m, ws, into)
             else:
-                dcur, grads = chan_attn_backward(dcur, saved, m, ws)
-            for k, v in grads.items():
-                put(f"blocks.{idx}.{k}", v)
+                dcur, _ = chan_attn_backward(dcur, saved, m, ws, into)
         # stem: x1 feeds the trunk and the long skip (gradient dm)
         dx1_pre, ds = prelu_scalar_bwd(S["x1_pre"], dcur, g.input[1].weight.detach(), ws, dy2=dm)
         put("input.1.weight", ds)
