@@ -58,7 +58,7 @@ inline uint16_t f32_to_bf16(float f)
 }
 
 struct ConvDev {           // offsets (bytes) into the device weight blob
-    size_t w_f32 = 0, w_wino = 0, w_bf16 = 0, bias = 0, slope = 0;
+    size_t w_f32 = 0, w_wino = 0, w_split = 0, w_bf16 = 0, bias = 0, slope = 0;
     bool has_slope = false;
     int cout_blocks = 1;
 };
@@ -78,6 +78,7 @@ struct srgen_handle {
     CaDev ca[2];
     size_t zeros = 0;              // kWinoZeroBytes of zeros in the blob (Winograd halo padding rows)
     bool f32_wino = true;          // fp32 3x3 convs: Winograd F(2x2,3x3) kernel (default) or the direct one
+    bool f32_split = false;        // ... or the split-f16 kernel (srgen_conv3x3_f32s.hip)
     // train-mode forward (srgen_forward_train): unfolded conv weights + BatchNorm affine parameters, built
     // lazily on the first train-mode call after a commit
     char* tblob = nullptr;         // device
@@ -205,6 +206,32 @@ std::vector<float> pack3x3_f32(const Folded& f, int cb, const std::vector<int>& 
     return p;
 }
 
+// split-f16 image (srgen_conv3x3_f32s.hip): every fp32 weight as hi = f16(w), lo = f16(w - hi); 16-byte units
+// [cb][ci chunk 6][ky 3][kx 3][co tile 3][hi|lo][lane 64] of 8 halfs: lane l holds co = 32 nt + (l & 31),
+// ci = 16 chunk + 8 (l >> 5) + e -- the MFMA A fragment of v_mfma_f32_32x32x16_f16.
+std::vector<uint16_t> pack3x3_split_f16(const Folded& f, int cb, const std::vector<int>& perm)
+{
+    std::vector<uint16_t> p((size_t)cb * 18 * 1152 * 8);
+    auto bits = [](_Float16 v) { uint16_t u; memcpy(&u, &v, 2); return u; };
+    for (int b = 0; b < cb; ++b)
+        for (int ch = 0; ch < 6; ++ch)
+            for (int ky = 0; ky < 3; ++ky)
+                for (int kx = 0; kx < 3; ++kx)
+                    for (int nt = 0; nt < 3; ++nt)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int e = 0; e < 8; ++e) {
+                                const int oc = perm[b * 96 + 32 * nt + (lane & 31)];
+                                const int ci = 16 * ch + 8 * (lane >> 5) + e;
+                                const float v = f.w[(((size_t)oc * 96 + ci) * 3 + ky) * 3 + kx];
+                                const _Float16 hi = (_Float16)v;
+                                const _Float16 lo = (_Float16)(v - (float)hi);
+                                const size_t unit = ((((((size_t)b * 6 + ch) * 3 + ky) * 3 + kx) * 3 + nt) * 2) * 64 + lane;
+                                p[unit * 8 + e] = bits(hi);
+                                p[(unit + 64) * 8 + e] = bits(lo);
+                            }
+    return p;
+}
+
 // fp32 Winograd image: U = G g Gt (F(2x2,3x3); G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]), formed in
 // fp64 from the folded weights and rounded once; float4 units [cb][nu 4][ci chunk 6][xi 4][ci/4 4]
 // [co 96] (4 consecutive ci per unit): one (cb, nu, chunk) slab is what srgen_conv3x3_f32_wino.hip
@@ -326,6 +353,7 @@ ConvDev emit_conv3x3(Blob& blob, const Folded& f, int cb, const std::vector<int>
     d.cout_blocks = cb;
     d.w_f32 = blob.put_f32(pack3x3_f32(f, cb, perm));
     d.w_wino = blob.put_f32(pack3x3_wino_f32(f, cb, perm));
+    d.w_split = blob.put_u16(pack3x3_split_f16(f, cb, perm));
     d.w_bf16 = blob.put_u16(pack3x3_bf16(f, cb, perm));
     std::vector<float> bias((size_t)cb * 96), slope((size_t)cb * 96, 1.f);
     for (int i = 0; i < cb * 96; ++i) {
@@ -399,7 +427,10 @@ int srgen_create(const srgen_config* cfg, srgen_handle** out)
     h->cfg = *cfg;
     h->device = dev;
     // development / test switch: SRGEN_F32_CONV3X3=direct selects the direct fp32 3x3 kernel
-    if (const char* e = getenv("SRGEN_F32_CONV3X3")) h->f32_wino = strcmp(e, "direct") != 0;
+    if (const char* e = getenv("SRGEN_F32_CONV3X3")) {
+        h->f32_split = strcmp(e, "split") == 0;
+        h->f32_wino = !h->f32_split && strcmp(e, "direct") != 0;
+    }
     *out = h;
     return SRGEN_OK;
 }
@@ -616,8 +647,8 @@ static int run_forward(srgen_handle* h, const void* x, void* y, void* workspace,
                     int shuffle) -> hipError_t {
         Conv3x3Args a;
         a.in = in; a.out = out;
-        const bool wino = !bf && h->f32_wino;
-        a.wpack = B + (bf ? d.w_bf16 : wino ? d.w_wino : d.w_f32);
+        const bool wino = !bf && h->f32_wino, split = !bf && h->f32_split;
+        a.wpack = B + (bf ? d.w_bf16 : split ? d.w_split : wino ? d.w_wino : d.w_f32);
         a.zeros = B + h->zeros;
         a.bias = F(d.bias);
         a.slope = d.has_slope ? F(d.slope) : nullptr;
@@ -626,7 +657,8 @@ static int run_forward(srgen_handle* h, const void* x, void* y, void* workspace,
         a.cout_blocks = d.cout_blocks; a.shuffle = shuffle;
         hipError_t e = tick(shuffle ? SRGEN_K_CONV3X3_UP : (H == kLR ? SRGEN_K_CONV3X3_TRUNK : SRGEN_K_CONV3X3_HR));
         if (e != hipSuccess) return e;
-        e = bf ? launch_conv3x3_bf16(a, s) : wino ? launch_conv3x3_f32_wino(a, s) : launch_conv3x3_f32(a, s);
+        e = bf ? launch_conv3x3_bf16(a, s) : split ? launch_conv3x3_f32_split(a, s)
+               : wino ? launch_conv3x3_f32_wino(a, s) : launch_conv3x3_f32(a, s);
         if (e != hipSuccess) return e;
         return tock();
     };

@@ -1,0 +1,349 @@
+// srgen_conv3x3_f32s.hip -- gfx950 3x3 conv 96 -> 96 (x cout_blocks) with fp32 tensors, fp32 accumulation and the
+// products formed on the f16 matrix instruction from two-term splits of both operands ("split" path).
+//
+// Reference sites: as srgen_conv3x3_f32.hip (Generator.py:34,37,62,7,69 with the folded BatchNorm; PReLU / residual /
+// PixelShuffle in the epilogue).
+//
+// Why.  The exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) runs at 1/16 of the f16 one (v_mfma_f32_32x32x16_f16).  An fp32
+// value x splits exactly into x = hi + lo + r with hi = f16(x), lo = f16(x - hi) and |r| <= 2^-22 |x| (f16 keeps 11
+// significant bits; its subnormals are kept by the matrix pipe -- probed with tools/f16denorm.cpp), products of two f16
+// numbers are exact in fp32, and the MFMA accumulates in fp32.  So
+//     x * w  =  hi_x hi_w + hi_x lo_w + lo_x hi_w  + O(2^-22 |x w|)
+// costs three f16 MFMAs = 3/16 of the exact-fp32 MFMA time (the Winograd kernel: 16/36 = 7/16), with the error of an
+// fp32 product (a numpy emulation of one 864-term layer: 8.2e-7 of max against 6.1e-7 for plain fp32 accumulation), and
+// none of Winograd's transform arithmetic or its 4 - 9x error growth.  Weights are split once on the host (fp64 fold ->
+// fp32 -> hi / lo); activations are split when the halo tile is staged into LDS, so tensors in HBM stay fp32.
+//
+// Skeleton = the direct fp32 kernel: persistent workgroups of 4 waves, work item = 4 rows x 64 pixels x 96 co, wave = one
+// row = 2 x 3 tiles of 32 x 32 (96 accumulators), weights = MFMA A operand so a lane ends with 4 consecutive channels of
+// one pixel per register group (16-byte NHWC stores).  K = 9 taps x 96 ci runs as 6 chunks of 16 ci (one MFMA K) x 3
+// kernel rows x 3 taps.  LDS: the halo tile of one chunk (6 x 66 pixels x {16 hi, 16 lo} f16, pixel pitch 80 B = 16 x odd:
+// conflict-free ds_read_b128) and a two-slot ring of weight groups (one kernel row of one chunk: 3 taps x 3 co tiles x
+// {hi, lo} x 64 lanes x 16 B = 18 KB, lane-ordered so a fragment is one ds_read_b128); the next group's weights and the
+// next chunk's pixels are fetched into registers under the MFMAs and written to LDS behind them.  One barrier per group
+// (54 MFMAs = 1,728 cycles), two at a chunk end; 71 KB of LDS, two workgroups per CU.
+#include "srgen_internal.h"
+
+#include <type_traits>
+
+namespace srgen {
+namespace c3s {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+#define MFMA_H(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+
+constexpr int TH = 4, TW = 64, HH = 6, HWP = 66;
+constexpr int CK = 16, NCH = 6;                   // ci per chunk, chunks
+constexpr int PSB = 80;                           // bytes per staged pixel: 16 hi | 16 lo | pad
+constexpr int A_BYTES = HH * HWP * PSB;           // 31,680
+constexpr int WG_UNITS = 3 * 3 * 2 * 64;          // 16-byte units of one weight group (kernel row of a chunk): 1,152
+constexpr int WG_BYTES = WG_UNITS * 16;           // 18,432
+constexpr int W_OFF = A_BYTES;
+constexpr int BS_OFF = W_OFF + 2 * WG_BYTES;      // bias[4][96], slope[4][96]
+constexpr int POOL_OFF = BS_OFF + 2 * 4 * 96 * 4;
+constexpr int LDS_BYTES = POOL_OFF + 4 * 96 * 4;  // 73,152 (two workgroups per CU)
+constexpr int A_ITEMS = HH * HWP * 4;             // float4 pieces per chunk (1,584)
+constexpr int A_REGS = 7;                         // ceil(1584 / 256)
+constexpr int W_REGS = 5;                         // ceil(1152 / 256)
+constexpr int MAX_WGS = 512;
+
+struct Frags { h8 xh[2], xl[2], wh[3], wl[3]; };
+
+__device__ __forceinline__ int opaque(int v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+// acc += hi_w hi_x + lo_w hi_x + hi_w lo_x, small terms first
+__device__ __forceinline__ void mma_tap(f32x16 (&acc)[2][3], const Frags& f)
+{
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            acc[mt][nt] = MFMA_H(f.wl[nt], f.xh[mt], acc[mt][nt]);
+            acc[mt][nt] = MFMA_H(f.wh[nt], f.xl[mt], acc[mt][nt]);
+            acc[mt][nt] = MFMA_H(f.wh[nt], f.xh[mt], acc[mt][nt]);
+        }
+}
+
+struct Item { int n, ty, tx, cb; };
+
+template <int HW, bool SHUFFLE, bool POOL, bool RES>
+__global__ __launch_bounds__(256, 2) void conv3x3_f32s_kernel(Conv3x3Args a, int nitems)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, p = lane & 31;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int tiles_x = HW / TW, tiles_y = HW / TH, tiles_img = tiles_x * tiles_y;
+    constexpr int CB = SHUFFLE ? 4 : 1;
+    const bool act = a.slope != nullptr;
+
+    // persistent item walk: XCD x owns items [x*per, (x+1)*per) (see srgen_conv3x3_bf16.hip)
+    const int per_xcd = nitems >> 3;
+    const int wg_per_xcd = (int)gridDim.x >> 3;
+    const int xcd = blockIdx.x & 7;
+    const int item_end = (xcd + 1) * per_xcd;
+    int item = xcd * per_xcd + ((int)blockIdx.x >> 3);
+    auto decode = [&](int it) {
+        Item r;
+        r.cb = it % CB;
+        const int tile = it / CB;
+        r.tx = tile % tiles_x;
+        r.ty = (tile / tiles_x) % tiles_y;
+        r.n = tile / tiles_img;
+        return r;
+    };
+
+    char* const ldsA = lds;
+    char* const ldsW = lds + W_OFF;
+    float* const ldsBias = (float*)(lds + BS_OFF);
+    float* const ldsSlope = ldsBias + 4 * 96;
+    float* const ldsPool = (float*)(lds + POOL_OFF);
+
+    // ---- halo tile staging: fp32 pieces -> registers (clamped address, validity bit) -> split -> LDS ----
+    f32x4 stage[A_REGS];
+    unsigned stage_ok = 0;
+    auto load_a = [&](const Item& t, int c) {
+        const float* in = (const float*)a.in + (size_t)t.n * HW * HW * kC + c * CK;
+        const int x0 = t.tx * TW, y0 = t.ty * TH;
+        const int tv = opaque(tid);
+        stage_ok = 0;
+#pragma unroll
+        for (int it = 0; it < A_REGS; ++it) {
+            const int i = min(tv + it * 256, A_ITEMS - 1);
+            const int pix = i >> 2, q = i & 3;
+            const int r = pix / HWP, cc = pix - r * HWP;
+            const int gy = y0 - 1 + r, gx = x0 - 1 + cc;
+            const bool ok = (unsigned)gy < (unsigned)HW && (unsigned)gx < (unsigned)HW;
+            const int cy = min(max(gy, 0), HW - 1), cx = min(max(gx, 0), HW - 1);
+            stage[it] = *(const f32x4*)(in + (cy * HW + cx) * kC + q * 4);
+            stage_ok |= (ok ? 1u : 0u) << it;
+        }
+    };
+    auto store_a = [&]() {
+        const int tv = opaque(tid);
+#pragma unroll
+        for (int it = 0; it < A_REGS; ++it) {
+            const int i = tv + it * 256;
+            const bool ok = (stage_ok >> it) & 1u;
+            h4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = ok ? stage[it][e] : 0.f;
+                hi[e] = (_Float16)v;
+                lo[e] = (_Float16)(v - (float)hi[e]);
+            }
+            if (i < A_ITEMS) {
+                char* rec = ldsA + (i >> 2) * PSB + (i & 3) * 8;
+                *(h4*)rec = hi;
+                *(h4*)(rec + 32) = lo;
+            }
+        }
+    };
+    // ---- weight groups: packed 16-byte units [cb][chunk 6][ky 3][kx 3][nt 3][hl 2][lane 64] ----
+    f32x4 wstage[W_REGS];
+    auto load_w = [&](int cb, int g) {
+        const f32x4* src = (const f32x4*)a.wpack + ((size_t)cb * 18 + g) * WG_UNITS;
+        const int tv = opaque(tid);
+#pragma unroll
+        for (int k = 0; k < W_REGS; ++k) wstage[k] = src[min(tv + 256 * k, WG_UNITS - 1)];
+    };
+    auto store_w = [&](int slot) {
+        f32x4* dst = (f32x4*)(ldsW + slot * WG_BYTES);
+        const int tv = opaque(tid);
+#pragma unroll
+        for (int k = 0; k < W_REGS; ++k)
+            if (tv + 256 * k < WG_UNITS) dst[tv + 256 * k] = wstage[k];
+    };
+    // residual of this lane's outputs, one 32-pixel M tile at a time (see srgen_conv3x3_f32.hip)
+    f32x4 rres[12];
+    auto load_res = [&](const Item& t, int mt) {
+        const int lv = opaque(lane);
+        const float* res = (const float*)a.res +
+                           (((size_t)t.n * HW + t.ty * TH + w) * HW + t.tx * TW + 32 * mt + (lv & 31)) * kC + 4 * (lv >> 5);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) rres[i] = *(const f32x4*)(res + 32 * (i >> 2) + 8 * (i & 3));
+    };
+
+    Item cur = decode(item);
+    load_a(cur, 0);
+    load_w(cur.cb, 0);
+    for (int i = tid; i < CB * 96; i += 256) {
+        ldsBias[i] = a.bias[i];
+        ldsSlope[i] = act ? a.slope[i] : 1.f;
+    }
+    store_a();
+    store_w(0);
+    __syncthreads();
+
+    // this lane's fragment addresses: pixel (row w + ky, column p + kx [+ 32]) of the halo tile, half h of the chunk
+    const char* const Ax = ldsA + (w * HWP + p) * PSB + 16 * h;
+    const char* const Wl = ldsW + lane * 16;
+
+#pragma unroll 1
+    for (;;) {
+        const int nxt = item + wg_per_xcd;
+        const bool has_next = nxt < item_end;
+        const Item nx = decode(has_next ? nxt : item);
+
+        // accumulators start at the bias (broadcast LDS reads: the address depends on h only)
+        f32x16 acc[2][3];
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+            for (int G = 0; G < 4; ++G) {
+                const f32x4 b4 = *(const f32x4*)(ldsBias + cur.cb * 96 + 32 * nt + 8 * G + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[0][nt][4 * G + e] = acc[1][nt][4 * G + e] = b4[e];
+            }
+
+        auto load_frags = [&](Frags& f, int slot, int ky, int kx) {
+            const char* ab = Ax + (ky * HWP + kx) * PSB;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                f.xh[mt] = *(const h8*)(ab + mt * 32 * PSB);
+                f.xl[mt] = *(const h8*)(ab + mt * 32 * PSB + 32);
+            }
+            const char* wb = Wl + slot * WG_BYTES + kx * (3 * 2 * 64 * 16);
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt) {
+                f.wh[nt] = *(const h8*)(wb + (nt * 2) * 1024);
+                f.wl[nt] = *(const h8*)(wb + (nt * 2 + 1) * 1024);
+            }
+        };
+
+        Frags f0, f1;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int g = c * 3 + ky, slot = g & 1;
+                // the next group's weights (this item's, or group 0 of the next item) and, in a chunk's last group, the
+                // next chunk's pixels fly under this group's MFMAs
+                if (g + 1 < 18) load_w(cur.cb, g + 1);
+                else load_w(nx.cb, 0);
+                if (ky == 2) {
+                    if (c + 1 < NCH) load_a(cur, c + 1);
+                    else load_a(nx, 0);
+                }
+                if (RES && c == NCH - 1 && ky == 2) load_res(cur, 0);
+                load_frags(f0, slot, ky, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                load_frags(f1, slot, ky, 1);
+                mma_tap(acc, f0);
+                __builtin_amdgcn_sched_barrier(0);
+                load_frags(f0, slot, ky, 2);
+                mma_tap(acc, f1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_tap(acc, f0);
+                __builtin_amdgcn_sched_barrier(0);
+                store_w(slot ^ 1);                    // that slot was last read in the previous group
+                if (ky == 2) {
+                    __syncthreads();                  // every wave is past its last read of this chunk's pixels
+                    store_a();
+                }
+                __syncthreads();
+            }
+        }
+
+        // ---- epilogue (registers only): PReLU -> (+ residual) -> 16-byte NHWC stores ---------------
+        const int y = cur.ty * TH + w, x0 = cur.tx * TW;
+        float* out = (float*)a.out;
+        constexpr int PXS = SHUFFLE ? 2 * kC : kC;
+        if (SHUFFLE)
+            out += (((size_t)cur.n * 2 * HW + 2 * y + (cur.cb >> 1)) * 2 * HW + 2 * (x0 + p) + (cur.cb & 1)) * kC + 4 * h;
+        else
+            out += (((size_t)cur.n * HW + y) * HW + x0 + p) * kC + 4 * h;
+        float psum[3][16];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            if (RES && mt == 1) load_res(cur, 1);
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt) {
+                f32x16& c = acc[mt][nt];
+#pragma unroll
+                for (int G = 0; G < 4; ++G) {
+                    f32x4 v = {c[4 * G], c[4 * G + 1], c[4 * G + 2], c[4 * G + 3]};
+                    if (act) {
+                        const f32x4 s4 = *(const f32x4*)(ldsSlope + cur.cb * 96 + 32 * nt + 8 * G + 4 * h);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.f ? v[e] : v[e] * s4[e];
+                    }
+                    if (RES) v += rres[nt * 4 + G];
+                    if (POOL) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) psum[nt][4 * G + e] = mt == 0 ? v[e] : psum[nt][4 * G + e] + v[e];
+                    }
+                    *(f32x4*)(out + (size_t)(32 * mt) * PXS + 32 * nt + 8 * G) = v;
+                }
+            }
+        }
+        if (POOL) {
+            // per-tile channel sums (ChannelAttention's pool), fixed order (see srgen_conv3x3_f32.hip); the halo tile
+            // and both weight slots already belong to the next item, so the four waves meet in a region of their own
+            float* P = ldsPool;
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt) {
+                float (&t)[16] = psum[nt];
+#pragma unroll
+                for (int k = 8, b = 1; k >= 1; k >>= 1, b <<= 1)
+#pragma unroll
+                    for (int i = 0; i < k; ++i) {
+                        const bool up = (lane & b) != 0;
+                        const float send = up ? t[i] : t[i + k];
+                        const float keep = up ? t[i + k] : t[i];
+                        t[i] = keep + __shfl_xor(send, b);
+                    }
+                t[0] += __shfl_xor(t[0], 16);
+                if ((lane & 16) == 0) {
+                    const int q = 8 * (lane & 1) + 4 * ((lane >> 1) & 1) + 2 * ((lane >> 2) & 1) + ((lane >> 3) & 1);
+                    P[w * kC + 32 * nt + (q & 3) + 8 * (q >> 2) + 4 * h] = t[0];
+                }
+            }
+            __syncthreads();
+            if (tid < kC) {
+                const float s = (P[tid] + P[kC + tid]) + (P[2 * kC + tid] + P[3 * kC + tid]);
+                a.pool_partial[((size_t)cur.n * tiles_img + cur.ty * tiles_x + cur.tx) * kC + tid] = s;
+            }
+            __syncthreads();                      // P is read before the next tile overwrites it
+        }
+        if (!has_next) break;
+        item = nxt;
+        cur = nx;
+    }
+}
+
+template <int HW, bool SHUFFLE, bool POOL, bool RES>
+hipError_t launch_one(const Conv3x3Args& a, hipStream_t s)
+{
+    const int nitems = a.N * (HW / TH) * (HW / TW) * (SHUFFLE ? 4 : 1);     // multiple of 16
+    const int grid = nitems < MAX_WGS ? nitems & ~7 : MAX_WGS;
+    hipLaunchKernelGGL((conv3x3_f32s_kernel<HW, SHUFFLE, POOL, RES>), dim3((unsigned)grid), dim3(256), LDS_BYTES,
+                       s, a, nitems);
+    return hipGetLastError();
+}
+
+}  // namespace c3s
+
+hipError_t launch_conv3x3_f32_split(const Conv3x3Args& a, hipStream_t s)
+{
+    using namespace c3s;
+    if (a.H != a.W || a.N <= 0) return hipErrorInvalidValue;
+    const bool res = a.res != nullptr, pool = a.pool_partial != nullptr;
+    if (a.H == kLR && !a.shuffle && a.cout_blocks == 1) {
+        if (!pool && !res) return launch_one<kLR, false, false, false>(a, s);
+        if (!pool && res) return launch_one<kLR, false, false, true>(a, s);
+        if (pool && res) return launch_one<kLR, false, true, true>(a, s);
+    }
+    if (a.H == kLR && a.shuffle && a.cout_blocks == 4 && !pool && !res) return launch_one<kLR, true, false, false>(a, s);
+    if (a.H == kHR && !a.shuffle && a.cout_blocks == 1 && !pool && !res) return launch_one<kHR, false, false, false>(a, s);
+    return hipErrorInvalidValue;
+}
+
+}  // namespace srgen

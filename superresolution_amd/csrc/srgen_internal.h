@@ -83,6 +83,8 @@ struct HeadArgs {
 // fp32 kernels (srgen_kernels_f32.hip)
 hipError_t launch_stem_f32(const StemArgs& a, hipStream_t s);
 hipError_t launch_conv3x3_f32(const Conv3x3Args& a, hipStream_t s);
+// fp32 tensors, f16 matrix instruction on two-term splits of both operands (srgen_conv3x3_f32s.hip)
+hipError_t launch_conv3x3_f32_split(const Conv3x3Args& a, hipStream_t s);
 // Winograd F(2x2,3x3) form of the same conv (srgen_conv3x3_f32_wino.hip); wpack = U = G g Gt packed
 // as float4 units [cb][nu 4][ci chunk 6][xi 4][ci/4 4][co 96]; needs Conv3x3Args::zeros; same
 // pool_partial tiling as the direct kernel
