@@ -161,14 +161,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32s_kernel(Conv3x3Args a, int
         for (int k = 0; k < W_REGS; ++k)
             if (tv + 256 * k < WG_UNITS) dst[tv + 256 * k] = wstage[k];
     };
-    // residual of this lane's outputs, one 32-pixel M tile at a time (see srgen_conv3x3_f32.hip)
-    f32x4 rres[12];
-    auto load_res = [&](const Item& t, int mt) {
+    // residual of this lane's outputs, one (32-pixel M tile, 32-channel N tile) at a time: four 16-byte pieces at
+    // channels 32 nt + 8 G + 4 h.  Two sets: the next tile's pieces are in flight while the current tile is finished
+    // (all twelve of an M tile at once cost 48 registers and spilled at two workgroups per CU)
+    f32x4 rres[2][4];
+    auto load_res = [&](const Item& t, int mt, int nt, int set) {
         const int lv = opaque(lane);
         const float* res = (const float*)a.res +
-                           (((size_t)t.n * HW + t.ty * TH + w) * HW + t.tx * TW + 32 * mt + (lv & 31)) * kC + 4 * (lv >> 5);
+                           (((size_t)t.n * HW + t.ty * TH + w) * HW + t.tx * TW + 32 * mt + (lv & 31)) * kC + 4 * (lv >> 5) + 32 * nt;
 #pragma unroll
-        for (int i = 0; i < 12; ++i) rres[i] = *(const f32x4*)(res + 32 * (i >> 2) + 8 * (i & 3));
+        for (int G = 0; G < 4; ++G) rres[set][G] = *(const f32x4*)(res + 8 * G);
     };
 
     Item cur = decode(item);
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32s_kernel(Conv3x3Args a, int
                     if (c + 1 < NCH) load_a(cur, c + 1);
                     else load_a(nx, 0);
                 }
-                if (RES && c == NCH - 1 && ky == 2) load_res(cur, 0);
+                if (RES && c == NCH - 1 && ky == 2) load_res(cur, 0, 0, 0);
                 load_frags(f0, slot, ky, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 load_frags(f1, slot, ky, 1);
@@ -263,9 +265,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32s_kernel(Conv3x3Args a, int
         float psum[3][16];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
-            if (RES && mt == 1) load_res(cur, 1);
 #pragma unroll
             for (int nt = 0; nt < 3; ++nt) {
+                const int k = mt * 3 + nt;
+                if (RES && k + 1 < 6) load_res(cur, (k + 1) / 3, (k + 1) % 3, (k + 1) & 1);
                 f32x16& c = acc[mt][nt];
 #pragma unroll
                 for (int G = 0; G < 4; ++G) {
@@ -275,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32s_kernel(Conv3x3Args a, int
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.f ? v[e] : v[e] * s4[e];
                     }
-                    if (RES) v += rres[nt * 4 + G];
+                    if (RES) v += rres[k & 1][G];
                     if (POOL) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) psum[nt][4 * G + e] = mt == 0 ? v[e] : psum[nt][4 * G + e] + v[e];
