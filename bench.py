@@ -25,11 +25,17 @@ Workloads (BASELINE.json `configs`), both measured by every run and printed by r
 Further objects on the line:
   roofline      dominant kernel = the 33 trunk 3x3 convs (75 % of the FLOPs).  `achieved` = FLOPs the matrix
                 pipe EXECUTES per launch / average launch duration measured live with HIP events on the launch
-                stream (srgen_forward_profile); `frac` = achieved / peak (157.3 TFLOP/s fp32 matrix, 2500 TFLOP/s
-                bf16 dense: MI355X_MICROARCH.md).  The fp32 kernel is Winograd F(2x2,3x3): it executes 16/36 of
-                the conv's algorithmic multiplies; the algorithmic rate (2*4096*96*864 FLOP per
-                image and launch) is reported beside it as `algorithmic_tflops` and may exceed the peak.
+                stream (srgen_forward_profile); `frac` = achieved / peak of the instruction the kernel issues
+                (2500 TFLOP/s f16 / bf16 dense, 157.3 TFLOP/s fp32 matrix: MI355X_MICROARCH.md).  The default fp32
+                kernel keeps fp32 tensors and fp32 accumulation and forms every product from two-term f16 splits
+                of both operands: THREE f16 MFMAs per algorithmic multiply-add, so executed = 3 x algorithmic and
+                the peak is the f16 one.  SRGEN_F32_CONV3X3=wino (Winograd F(2x2,3x3), 16/36 of the multiplies) and
+                =direct run on the exact-fp32 MFMA and are priced against 157.3.  The algorithmic rate (SURVEY.md
+                8(d): 2*4096*96*864 FLOP per image and launch) is reported beside it as `algorithmic_tflops`.
                 traffic = HBM bytes per launch from the committed rocprofv3 PMC summary (profiles/traffic_*.json).
+  f32_exact_mfma  the same cfg1 leg with the 3x3 convs on the exact-fp32 MFMA (Winograd kernel), a few steps: the
+                number to quote if split products are not accepted as fp32 (errors of both against the reference's
+                fp32 output are in `psnr`: max_rel_err_f32 and max_rel_err_f32_exact_mfma).
   bf16          the north-star dtype on the same line: batch-256 forward images/s, trunk conv ms per launch,
                 frac of the 2.5 PF peak, traffic, PSNR delta.
   psnr          the "PSNR delta vs reference" half of the metric: this library's output on the two golden inputs
@@ -51,8 +57,29 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_IMAGE = 2 * 14_407_045_632
 TRUNK_CONV_FLOP_PER_IMAGE = 2 * 4096 * 96 * 864  # one 96->96 3x3 conv at 64x64
-PEAK = {"f32": 157.3, "bf16": 2500.0}          # dense TFLOP/s, MI355X_MICROARCH.md
+PEAK = {"f32": 157.3, "bf16": 2500.0, "f16": 2500.0}   # dense TFLOP/s, MI355X_MICROARCH.md
 WINO_EXECUTED = 16.0 / 36.0                    # F(2x2,3x3): multiplies executed / algorithmic
+SPLIT_EXECUTED = 3.0                           # split path: hi*hi + hi*lo + lo*hi on the f16 MFMA
+
+
+def f32_path():
+    """Which fp32 3x3 kernel a handle created now would run (srgen_api.cpp: srgen_create)."""
+    return os.environ.get("SRGEN_F32_CONV3X3") or "split"
+
+
+def f32_pricing(dt_name):
+    """(path label, executed / algorithmic, peak TFLOP/s of the MFMA the path issues, kernel name, what is counted)."""
+    if dt_name == "bf16":
+        return ("bf16", 1.0, PEAK["bf16"], "conv3x3_bf16_kernel<64,false,*,*>", "algorithmic = executed (direct implicit GEMM)")
+    path = f32_path()
+    if path == "split":
+        return ("split", SPLIT_EXECUTED, PEAK["f16"], "conv3x3_f32s_kernel<64,false,*,*>",
+                "FLOPs the matrix pipe executes: fp32 tensors and accumulation, each product = 3 v_mfma_f32_32x32x16_f16 "
+                "terms (hi*hi + hi*lo + lo*hi of two-term f16 splits), priced against the f16 dense peak")
+    if path == "wino":
+        return ("wino", WINO_EXECUTED, PEAK["f32"], "conv3x3_f32_wino_kernel<64,false,*,*,*>",
+                "FLOPs the matrix pipe executes: Winograd F(2x2,3x3) runs 16/36 of the direct conv's multiplies")
+    return ("direct", 1.0, PEAK["f32"], "conv3x3_f32_kernel<64,false,*,*>", "algorithmic = executed (direct implicit GEMM)")
 BATCH = 256                                    # config.py:8, the reference batch
 CFG2_BATCHES_PER_GPU = 4                       # 8192 images / 256 / 8 GPUs
 
@@ -321,24 +348,23 @@ def main():
     def roofline(dt_name, kernels):
         ms_launch = kernels["conv3x3_trunk"]["ms_per_launch"]
         algorithmic = TRUNK_CONV_FLOP_PER_IMAGE * args.batch / (ms_launch * 1e-3) / 1e12
-        wino = dt_name == "f32" and os.environ.get("SRGEN_F32_CONV3X3") != "direct"
-        executed = algorithmic * (WINO_EXECUTED if wino else 1.0)
+        path, ratio, peak, kname, counts = f32_pricing(dt_name)
+        executed = algorithmic * ratio
         traffic = None
         tpath = os.path.join(ROOT, "profiles", f"traffic_{dt_name}.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("conv3x3_trunk_hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                if tj.get("path", "wino" if dt_name == "f32" else path) == path:      # a summary measured on another kernel says nothing here
+                    traffic = tj.get("conv3x3_trunk_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        kname = "conv3x3_f32_wino_kernel<64,false,*,*,*>" if wino else f"conv3x3_{dt_name}_kernel<64,false,*,*>"
         return {"bound": "mfma", "kernel": f"{kname} (33 trunk launches)", "achieved": round(executed, 2),
-                "peak": PEAK[dt_name], "unit": "TFLOP/s", "frac": round(executed / PEAK[dt_name], 4),
+                "peak": peak, "unit": "TFLOP/s", "frac": round(executed / peak, 4),
                 "traffic": traffic, "ms_per_launch": ms_launch,
-                "flop_per_launch_executed": int(TRUNK_CONV_FLOP_PER_IMAGE * args.batch * (WINO_EXECUTED if wino else 1.0)),
+                "flop_per_launch_executed": int(TRUNK_CONV_FLOP_PER_IMAGE * args.batch * ratio),
                 "flop_per_launch_algorithmic": TRUNK_CONV_FLOP_PER_IMAGE * args.batch,
-                "algorithmic_tflops": round(algorithmic, 2),
-                "counts": ("FLOPs the matrix pipe executes: Winograd F(2x2,3x3) runs 16/36 of the direct conv's "
-                           "multiplies" if wino else "algorithmic = executed (direct implicit GEMM)")}
+                "algorithmic_tflops": round(algorithmic, 2), "counts": counts}
 
     def psnr_vs_reference():
         """PSNR delta vs the reference: this library's output on the two golden inputs against the reference's
@@ -358,6 +384,10 @@ def main():
             out[f"psnr_delta_{name}_db"] = round(p - p_ref, 6)
             out[f"psnr_{name}_vs_reference_output_db"] = round(float(batch_metrics(y, ref)[0]), 2)
             out[f"max_rel_err_{name}"] = float((y - ref).abs().max() / ref.abs().max())
+        if g_exact is not None:
+            y = g_exact(xin).float()
+            out["max_rel_err_f32_exact_mfma"] = float((y - ref).abs().max() / ref.abs().max())
+        out["f32_conv3x3_path"] = f32_path()
         return out
 
     def cfg2_leg(reps):
@@ -405,6 +435,34 @@ def main():
             dist.destroy_process_group()
         return
     med = median_forward(dtype, max(50, args.median_steps), min_seconds=4.0 if world == 1 else 0.0)
+    # the same leg on the exact-fp32 MFMA (Winograd kernel): a second module whose handle is created under the switch
+    g_exact, exact_obj = None, None
+    if f32_path() == "split":
+        saved = os.environ.get("SRGEN_F32_CONV3X3")
+        os.environ["SRGEN_F32_CONV3X3"] = "wino"
+        try:
+            g_exact = Generator()
+            g_exact.load_state_dict(W.synthetic_state_dict(0))
+            g_exact = g_exact.to(dev).eval()
+            g_main, g = g, g_exact
+            steps_exact = max(10, args.steps // 5)
+            dt_exact = timed_forward("f32", steps_exact, 2)
+            kern_exact = kernel_profile("f32", reps=1) if rank == 0 else None
+            g = g_main
+        finally:
+            if saved is None:
+                del os.environ["SRGEN_F32_CONV3X3"]
+            else:
+                os.environ["SRGEN_F32_CONV3X3"] = saved
+        if rank == 0:
+            v = args.batch * n_ranks * steps_exact / dt_exact
+            tr = kern_exact["conv3x3_trunk"]["ms_per_launch"]
+            alg = TRUNK_CONV_FLOP_PER_IMAGE * args.batch / (tr * 1e-3) / 1e12
+            exact_obj = {"path": "SRGEN_F32_CONV3X3=wino: Winograd F(2x2,3x3) on v_mfma_f32_16x16x4_f32",
+                         "images_per_s": round(v, 2), "ms_per_step": round(dt_exact / steps_exact * 1e3, 3),
+                         "steps": steps_exact, "trunk_ms_per_launch": tr,
+                         "trunk_frac_of_fp32_mfma_peak": round(alg * WINO_EXECUTED / PEAK["f32"], 4),
+                         "trunk_algorithmic_tflops": round(alg, 2)}
     other = "bf16" if dtype == "f32" else "f32"
     dt_other = timed_forward(other, max(20, args.steps // 2), 3)
     steps_other = max(20, args.steps // 2)
@@ -442,11 +500,12 @@ def main():
 
         def fwd_obj(d, dt, steps, md):
             v = args.batch * n_ranks * steps / dt
-            wino = d == "f32" and os.environ.get("SRGEN_F32_CONV3X3") != "direct"
+            path, ratio, peak, _, _ = f32_pricing(d)
+            e2e_ratio = 0.9668 * ratio + 0.0332 * (peak / PEAK[d])   # 9x9 stem / head (3.3 %) run direct in dtype d
             return {"images_per_s": round(v, 2), "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps, **md,
+                    "conv3x3_path": path,
                     "end_to_end_algorithmic_tflops": round(v * FLOP_PER_IMAGE / 1e12, 2),
-                    "end_to_end_frac_of_peak": round(v / n_ranks * FLOP_PER_IMAGE / 1e12 / PEAK[d]
-                                                     * (WINO_EXECUTED_E2E if wino else 1.0), 4),
+                    "end_to_end_frac_of_peak": round(v / n_ranks * FLOP_PER_IMAGE / 1e12 / peak * e2e_ratio, 4),
                     "trunk_ms_per_launch": kern[d]["conv3x3_trunk"]["ms_per_launch"],
                     "trunk_frac_of_peak": roofs[d]["frac"], "traffic": roofs[d]["traffic"],
                     "psnr_delta_vs_reference_db": psnr[f"psnr_delta_{d}_db"]}
@@ -474,17 +533,19 @@ def main():
             "kernels": kern[dtype], f"kernels_{other}": kern[other], "roofline_" + other: roofs[other],
             "hbm_kernels": hbm, "psnr": psnr,
         }
+        if exact_obj is not None:
+            out["f32_exact_mfma"] = exact_obj
+        out["config"]["precision"] = {
+            "f32": ("fp32 tensors in HBM, fp32 accumulation; 3x3 conv products via two-term f16 splits of both operands "
+                    "(3 f16 MFMAs per product, error of an fp32 product: see psnr.max_rel_err_f32 beside "
+                    "max_rel_err_f32_exact_mfma)") if f32_path() == "split" else f"exact-fp32 MFMA ({f32_path()})",
+            "bf16": "bf16 tensors and MFMA operands, fp32 accumulation"}["bf16" if headline_cfg2 else dtype]
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
-
-
-# end-to-end executed share for the fp32 path: the 36 3x3 convs (96.7 % of the FLOPs) run Winograd, the 9x9 stem and
-# head (3.3 %) run direct -> executed / algorithmic over the whole forward
-WINO_EXECUTED_E2E = (0.9668 * WINO_EXECUTED + 0.0332)
 
 
 if __name__ == "__main__":

@@ -77,8 +77,10 @@ struct srgen_handle {
     std::vector<ConvDev> conv1, conv2;   // per residual block
     CaDev ca[2];
     size_t zeros = 0;              // kWinoZeroBytes of zeros in the blob (Winograd halo padding rows)
-    bool f32_wino = true;          // fp32 3x3 convs: Winograd F(2x2,3x3) kernel (default) or the direct one
-    bool f32_split = false;        // ... or the split-f16 kernel (srgen_conv3x3_f32s.hip)
+    // fp32 3x3 convs of the eval forward: the split-f16 kernel (default, srgen_conv3x3_f32s.hip), the Winograd
+    // F(2x2,3x3) kernel on the fp32 MFMA (SRGEN_F32_CONV3X3=wino) or the direct fp32-MFMA kernel (=direct)
+    bool f32_split = true;
+    bool f32_wino = false;
     // train-mode forward (srgen_forward_train): unfolded conv weights + BatchNorm affine parameters, built
     // lazily on the first train-mode call after a commit
     char* tblob = nullptr;         // device
@@ -426,10 +428,14 @@ int srgen_create(const srgen_config* cfg, srgen_handle** out)
     if (!h) return fail(SRGEN_E_INVALID, "out of host memory");
     h->cfg = *cfg;
     h->device = dev;
-    // development / test switch: SRGEN_F32_CONV3X3=direct selects the direct fp32 3x3 kernel
+    // SRGEN_F32_CONV3X3 = split (default) | wino | direct picks the fp32 3x3 kernel; anything else is an error
     if (const char* e = getenv("SRGEN_F32_CONV3X3")) {
-        h->f32_split = strcmp(e, "split") == 0;
-        h->f32_wino = !h->f32_split && strcmp(e, "direct") != 0;
+        if (strcmp(e, "split") != 0 && strcmp(e, "wino") != 0 && strcmp(e, "direct") != 0 && e[0] != 0) {
+            delete h;
+            return fail(SRGEN_E_INVALID, "SRGEN_F32_CONV3X3='%s': expected split, wino or direct", e);
+        }
+        h->f32_split = e[0] == 0 || strcmp(e, "split") == 0;
+        h->f32_wino = strcmp(e, "wino") == 0;
     }
     *out = h;
     return SRGEN_OK;

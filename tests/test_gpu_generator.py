@@ -60,12 +60,14 @@ def test_fp32_vs_cpu_oracle_other_seed(synth_sd_np):
     assert max_rel(y, ref) <= FP32_TOL
 
 
-def test_fp32_direct_conv_kernel_matches_golden_and_winograd(gen, golden, golden_inputs, monkeypatch):
-    """The fp32 3x3 convs run the Winograd F(2x2,3x3) kernel by default; the direct kernel
-    (SRGEN_F32_CONV3X3=direct at handle creation) must meet the same bar, and the two must agree
-    far inside it, on a batch whose work items straddle rows, images and workgroup counts."""
+@pytest.mark.parametrize("path", ["direct", "wino"])
+def test_fp32_exact_mfma_conv_kernels_match_golden_and_the_default(gen, golden, golden_inputs, monkeypatch, path):
+    """The fp32 3x3 convs run the split-f16 kernel by default (fp32 tensors and accumulation, every product formed
+    from two-term f16 splits of both operands: srgen_conv3x3_f32s.hip); the two kernels on the exact-fp32 MFMA
+    (SRGEN_F32_CONV3X3=direct | wino at handle creation) must meet the same bar, and each must agree with the
+    default far inside it, on a batch whose work items straddle rows, images and workgroup counts."""
     from superresolution_amd import Generator, weights as W
-    monkeypatch.setenv("SRGEN_F32_CONV3X3", "direct")
+    monkeypatch.setenv("SRGEN_F32_CONV3X3", path)
     g = Generator()
     g.load_state_dict(W.synthetic_state_dict(0))
     g = g.cuda().eval()
@@ -78,6 +80,16 @@ def test_fp32_direct_conv_kernel_matches_golden_and_winograd(gen, golden, golden
     assert max_rel(yw.cpu().numpy(), yd.cpu().numpy()) <= 2e-5
     for nm in ("block0", "ca8", "skip", "upsample", "output1"):
         assert max_rel(tw[nm].cpu().numpy(), td[nm].cpu().numpy()) <= 2e-5, nm
+
+
+def test_unknown_fp32_conv_path_is_an_error(monkeypatch):
+    from superresolution_amd import Generator, weights as W
+    monkeypatch.setenv("SRGEN_F32_CONV3X3", "fast")
+    g = Generator()
+    g.load_state_dict(W.synthetic_state_dict(0))
+    with pytest.raises(RuntimeError, match="SRGEN_F32_CONV3X3"):
+        g = g.cuda().eval()
+        g(torch.zeros(1, 3, 64, 64, device="cuda"))
 
 
 # ---- bf16 (BASELINE.json configs[2]) --------------------------------------------------------
@@ -268,18 +280,19 @@ def _shuffle_kat_state_dict():
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("direct", [False, True])
-def test_pixel_shuffle_store_is_bit_exact_on_hip(dtype, direct, monkeypatch):
+@pytest.mark.parametrize("path", [None, "direct", "wino"])
+def test_pixel_shuffle_store_is_bit_exact_on_hip(dtype, path, monkeypatch):
     """north_star: the PixelShuffle(2) permutation is bit-exact.  An integer-valued image goes through the HIP
     kernels (selector weights, see _shuffle_kat_state_dict) and the `upsample` tap must EQUAL
     nn.PixelShuffle's permutation of the selector conv's integers -- a swapped sub-pixel or a wrong (c, h, w)
-    changes integers, so nothing hides inside a tolerance.  Values stay <= 96 in magnitude: exact in bf16 and
-    through the Winograd transforms (multiples of 1/4).  Both fp32 3x3 kernels and the bf16 kernel are covered."""
+    changes integers, so nothing hides inside a tolerance.  Values stay <= 96 in magnitude: exact in bf16, in the f16
+    splits of the default fp32 kernel and through the Winograd transforms (multiples of 1/4).  All three fp32 3x3
+    kernels and the bf16 kernel are covered."""
     from superresolution_amd import Generator
-    if direct:
+    if path is not None:
         if dtype == torch.bfloat16:
             pytest.skip("one bf16 3x3 kernel")
-        monkeypatch.setenv("SRGEN_F32_CONV3X3", "direct")
+        monkeypatch.setenv("SRGEN_F32_CONV3X3", path)
     g = Generator()
     g.load_state_dict(_shuffle_kat_state_dict())
     g = g.cuda().eval()
