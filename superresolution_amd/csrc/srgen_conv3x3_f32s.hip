@@ -48,7 +48,6 @@ constexpr int POOL_OFF = BS_OFF + 2 * 4 * 96 * 4;
 constexpr int LDS_BYTES = POOL_OFF + 4 * 96 * 4;  // 73,152 (two workgroups per CU)
 constexpr int A_ITEMS = HH * HWP * 4;             // float4 pieces per chunk (1,584)
 constexpr int A_REGS = 7;                         // ceil(1584 / 256)
-constexpr int W_REGS = 5;                         // ceil(1152 / 256)
 constexpr int MAX_WGS = 512;
 
 struct Frags { h8 xh[2], xl[2], wh[3], wl[3]; };
@@ -74,7 +73,8 @@ __device__ __forceinline__ void mma_tap(f32x16 (&acc)[2][3], const Frags& f)
 
 struct Item { int n, ty, tx, cb; };
 
-template <int HW, bool SHUFFLE, bool POOL, bool RES>
+// ABL: timing ablations for tools/bench_f32s.hip only (wrong results); the library instantiates ABL = 0
+template <int HW, bool SHUFFLE, bool POOL, bool RES, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_f32s_kernel(Conv3x3Args a, int nitems)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -106,60 +106,74 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32s_kernel(Conv3x3Args a, int
     float* const ldsSlope = ldsBias + 4 * 96;
     float* const ldsPool = (float*)(lds + POOL_OFF);
 
-    // ---- halo tile staging: fp32 pieces -> registers (clamped address, validity bit) -> split -> LDS ----
+    // ---- halo tile staging: fp32 pieces -> registers -> split (under the MFMAs) -> LDS ----------------------------
+    // Per item every thread keeps the image-relative offsets of its seven 16-byte pieces (clamped into the image) and a
+    // validity bit each; a chunk's load is then seven loads at offset + 16 c.
     f32x4 stage[A_REGS];
-    unsigned stage_ok = 0;
-    auto load_a = [&](const Item& t, int c) {
-        const float* in = (const float*)a.in + (size_t)t.n * HW * HW * kC + c * CK;
+    h4 chi[A_REGS], clo[A_REGS];
+    int aoff[A_REGS];
+    unsigned aok = 0;
+    auto plan_a = [&](const Item& t) {
         const int x0 = t.tx * TW, y0 = t.ty * TH;
-        const int tv = opaque(tid);
-        stage_ok = 0;
+        aok = 0;
 #pragma unroll
         for (int it = 0; it < A_REGS; ++it) {
-            const int i = min(tv + it * 256, A_ITEMS - 1);
+            const int i = min(tid + it * 256, A_ITEMS - 1);
             const int pix = i >> 2, q = i & 3;
             const int r = pix / HWP, cc = pix - r * HWP;
             const int gy = y0 - 1 + r, gx = x0 - 1 + cc;
             const bool ok = (unsigned)gy < (unsigned)HW && (unsigned)gx < (unsigned)HW;
             const int cy = min(max(gy, 0), HW - 1), cx = min(max(gx, 0), HW - 1);
-            stage[it] = *(const f32x4*)(in + (cy * HW + cx) * kC + q * 4);
-            stage_ok |= (ok ? 1u : 0u) << it;
+            aoff[it] = (cy * HW + cx) * kC + q * 4;
+            aok |= (ok ? 1u : 0u) << it;
+        }
+    };
+    auto load_a = [&](const Item& t, int c) {
+        const float* in = (const float*)a.in + (size_t)t.n * HW * HW * kC + c * CK;
+#pragma unroll
+        for (int it = 0; it < A_REGS; ++it) stage[it] = *(const f32x4*)(in + aoff[it]);
+    };
+    auto convert_a = [&](int it) {
+        const bool ok = (aok >> it) & 1u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float v = ok ? stage[it][e] : 0.f;
+            chi[it][e] = (_Float16)v;
+            clo[it][e] = (_Float16)(v - (float)chi[it][e]);
         }
     };
     auto store_a = [&]() {
-        const int tv = opaque(tid);
 #pragma unroll
         for (int it = 0; it < A_REGS; ++it) {
-            const int i = tv + it * 256;
-            const bool ok = (stage_ok >> it) & 1u;
-            h4 hi, lo;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float v = ok ? stage[it][e] : 0.f;
-                hi[e] = (_Float16)v;
-                lo[e] = (_Float16)(v - (float)hi[e]);
-            }
-            if (i < A_ITEMS) {
+            const int i = tid + it * 256;
+            if (it < A_REGS - 1 || i < A_ITEMS) {
                 char* rec = ldsA + (i >> 2) * PSB + (i & 3) * 8;
-                *(h4*)rec = hi;
-                *(h4*)(rec + 32) = lo;
+                *(h4*)rec = chi[it];
+                *(h4*)(rec + 32) = clo[it];
             }
         }
     };
-    // ---- weight groups: packed 16-byte units [cb][chunk 6][ky 3][kx 3][nt 3][hl 2][lane 64] ----
-    f32x4 wstage[W_REGS];
-    auto load_w = [&](int cb, int g) {
-        const f32x4* src = (const f32x4*)a.wpack + ((size_t)cb * 18 + g) * WG_UNITS;
-        const int tv = opaque(tid);
+    // ---- weight groups: packed 16-byte units [cb][chunk 6][ky 3][kx 3][nt 3][hl 2][lane 64], copied global -> LDS
+    // without registers: 18 pieces of 1 KB per group, wave w takes pieces w, w + 4, ... (see glds16_raw in
+    // srgen_conv3x3_bf16.hip for why this is inline asm; the copies are waited for with vmcnt(0) before the barrier
+    // that publishes the slot) ----
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+    auto issue_w = [&](int cb, int g, int slot) {
+        const char* src = (const char*)a.wpack + ((size_t)cb * 18 + g) * WG_BYTES;
 #pragma unroll
-        for (int k = 0; k < W_REGS; ++k) wstage[k] = src[min(tv + 256 * k, WG_UNITS - 1)];
+        for (int k = 0; k < 5; ++k) {
+            const int piece = w + 4 * k;
+            if (piece < 18) {
+                const unsigned la = lds_base + W_OFF + slot * WG_BYTES + piece * 1024;
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                             :: "v"((unsigned)(piece * 1024 + lane * 16)), "s"(src), "s"(la) : "memory", "m0");
+            }
+        }
     };
-    auto store_w = [&](int slot) {
-        f32x4* dst = (f32x4*)(ldsW + slot * WG_BYTES);
-        const int tv = opaque(tid);
-#pragma unroll
-        for (int k = 0; k < W_REGS; ++k)
-            if (tv + 256 * k < WG_UNITS) dst[tv + 256 * k] = wstage[k];
+    auto wait_all = [&]() { __builtin_amdgcn_s_waitcnt(0x0070); };            // vmcnt(0) lgkmcnt(0)
+    auto barrier = [&]() {
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
     };
     // residual of this lane's outputs, one (32-pixel M tile, 32-channel N tile) at a time: four 16-byte pieces at
     // channels 32 nt + 8 G + 4 h.  Two sets: the next tile's pieces are in flight while the current tile is finished
@@ -174,15 +188,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32s_kernel(Conv3x3Args a, int
     };
 
     Item cur = decode(item);
+    plan_a(cur);
     load_a(cur, 0);
-    load_w(cur.cb, 0);
+    issue_w(cur.cb, 0, 0);
     for (int i = tid; i < CB * 96; i += 256) {
         ldsBias[i] = a.bias[i];
         ldsSlope[i] = act ? a.slope[i] : 1.f;
     }
+#pragma unroll
+    for (int it = 0; it < A_REGS; ++it) convert_a(it);
     store_a();
-    store_w(0);
-    __syncthreads();
+    wait_all();
+    barrier();
 
     // this lane's fragment addresses: pixel (row w + ky, column p + kx [+ 32]) of the halo tile, half h of the chunk
     const char* const Ax = ldsA + (w * HWP + p) * PSB + 16 * h;
@@ -226,31 +243,73 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32s_kernel(Conv3x3Args a, int
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
                 const int g = c * 3 + ky, slot = g & 1;
-                // the next group's weights (this item's, or group 0 of the next item) and, in a chunk's last group, the
-                // next chunk's pixels fly under this group's MFMAs
-                if (g + 1 < 18) load_w(cur.cb, g + 1);
-                else load_w(nx.cb, 0);
-                if (ky == 2) {
-                    if (c + 1 < NCH) load_a(cur, c + 1);
-                    else load_a(nx, 0);
+                // the next group's weights (this item's, or group 0 of the next item) go to the other slot (last read
+                // in the previous group, every wave is past the barrier that ended it); in a chunk's first group the
+                // next chunk's pixels are fetched, in its last they are split into (hi, lo) between the MFMAs
+                if (!(ABL & 16)) {
+                    if (g + 1 < 18) issue_w(cur.cb, g + 1, slot ^ 1);
+                    else issue_w(nx.cb, 0, slot ^ 1);
+                    if (ky == 0) {
+                        if (c + 1 < NCH) load_a(cur, c + 1);
+                        else {
+                            plan_a(nx);
+                            load_a(nx, 0);
+                        }
+                    }
                 }
-                if (RES && c == NCH - 1 && ky == 2) load_res(cur, 0, 0, 0);
-                load_frags(f0, slot, ky, 0);
+                const bool cvt = ky == 2 && !(ABL & 1);
+                if (!(ABL & 8) || g == 0) load_frags(f0, slot, ky, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                load_frags(f1, slot, ky, 1);
-                mma_tap(acc, f0);
-                __builtin_amdgcn_sched_barrier(0);
-                load_frags(f0, slot, ky, 2);
-                mma_tap(acc, f1);
-                __builtin_amdgcn_sched_barrier(0);
-                mma_tap(acc, f0);
-                __builtin_amdgcn_sched_barrier(0);
-                store_w(slot ^ 1);                    // that slot was last read in the previous group
-                if (ky == 2) {
-                    __syncthreads();                  // every wave is past its last read of this chunk's pixels
-                    store_a();
+                if (!(ABL & 8) || g == 0) load_frags(f1, slot, ky, 1);
+                if (cvt) {
+                    convert_a(0);
+                    convert_a(1);
                 }
-                __syncthreads();
+                if (!(ABL & 4)) mma_tap(acc, f0);
+                if (cvt) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
+#pragma unroll
+                    for (int i = 0; i < 18; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (!(ABL & 8)) load_frags(f0, slot, ky, 2);
+                if (cvt) {
+                    convert_a(2);
+                    convert_a(3);
+                    convert_a(4);
+                }
+                if (!(ABL & 4)) mma_tap(acc, f1);
+                if (cvt) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
+#pragma unroll
+                    for (int i = 0; i < 18; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (cvt) {
+                    convert_a(5);
+                    convert_a(6);
+                }
+                if (!(ABL & 4)) mma_tap(acc, f0);
+                if (cvt) {
+#pragma unroll
+                    for (int i = 0; i < 18; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (ky == 2) {
+                    if (!(ABL & 2)) barrier();        // every wave is past its last read of this chunk's pixels
+                    if (!(ABL & 1)) store_a();
+                }
+                wait_all();                           // this wave's pixel stores and weight copies have landed
+                if (!(ABL & 64)) barrier();
             }
         }
 
@@ -263,6 +322,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32s_kernel(Conv3x3Args a, int
         else
             out += (((size_t)cur.n * HW + y) * HW + x0 + p) * kC + 4 * h;
         float psum[3][16];
+        if (RES) load_res(cur, 0, 0, 0);          // (earlier, under the last MFMAs, it costs registers that spill)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
