@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32s_kernel(Conv3x3Args a, int
         }
     };
     auto load_a = [&](const Item& t, int c) {
-        const float* in = (const float*)a.in + (size_t)t.n * HW * HW * kC + c * CK;
+        const float* in = (const float*)a.in + (size_t)((ABL & 2048) ? 0 : t.n) * HW * HW * kC + c * CK;
 #pragma unroll
         for (int it = 0; it < A_REGS; ++it) stage[it] = *(const f32x4*)(in + aoff[it]);
     };
@@ -175,18 +175,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32s_kernel(Conv3x3Args a, int
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
-    // residual of this lane's outputs, one (32-pixel M tile, 32-channel N tile) at a time: four 16-byte pieces at
-    // channels 32 nt + 8 G + 4 h.  Two sets: the next tile's pieces are in flight while the current tile is finished
-    // (all twelve of an M tile at once cost 48 registers and spilled at two workgroups per CU)
-    f32x4 rres[2][4];
-    auto load_res = [&](const Item& t, int mt, int nt, int set) {
-        const int lv = opaque(lane);
+    // residual of this lane's outputs: per (32-pixel M tile, 32-channel N tile) four 16-byte pieces at channels
+    // 32 nt + 8 G + 4 h.  Tile 0 is fetched under the last 18 MFMAs of the item (into registers the second fragment set
+    // has just left), the other five behind the item's last barrier, when fragments and staging registers are free
+    f32x4 rres[6][4];
+    auto load_res = [&](const Item& t, int k) {
+        const int mt = k / 3, nt = k % 3;
         const float* res = (const float*)a.res +
-                           (((size_t)t.n * HW + t.ty * TH + w) * HW + t.tx * TW + 32 * mt + (lv & 31)) * kC + 4 * (lv >> 5) + 32 * nt;
+                           (((size_t)t.n * HW + t.ty * TH + w) * HW + t.tx * TW + 32 * mt + p) * kC + 4 * h + 32 * nt;
 #pragma unroll
-        for (int G = 0; G < 4; ++G) rres[set][G] = *(const f32x4*)(res + 8 * G);
+        for (int G = 0; G < 4; ++G) rres[k][G] = *(const f32x4*)(res + 8 * G);
     };
 
+    long long t_start = 0;
+    if (ABL & 256) t_start = clock64();
     Item cur = decode(item);
     plan_a(cur);
     load_a(cur, 0);
@@ -295,6 +297,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32s_kernel(Conv3x3Args a, int
                     convert_a(5);
                     convert_a(6);
                 }
+                if (RES && g == 17) load_res(cur, 0);
                 if (!(ABL & 4)) mma_tap(acc, f0);
                 if (cvt) {
 #pragma unroll
@@ -308,7 +311,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32s_kernel(Conv3x3Args a, int
                     if (!(ABL & 2)) barrier();        // every wave is past its last read of this chunk's pixels
                     if (!(ABL & 1)) store_a();
                 }
-                wait_all();                           // this wave's pixel stores and weight copies have landed
+                // this wave's weight copies (and pixel stores) have landed.  In a chunk's first group the seven pixel
+                // loads issued after the copies may stay in flight (loads return in order): they are first needed in
+                // the chunk's last group, and an HBM miss takes about as long as one group
+                if (ky == 0 && !(ABL & 1024)) __builtin_amdgcn_s_waitcnt(0x0077);      // vmcnt(7) lgkmcnt(0)
+                else wait_all();
                 if (!(ABL & 64)) barrier();
             }
         }
@@ -322,13 +329,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32s_kernel(Conv3x3Args a, int
         else
             out += (((size_t)cur.n * HW + y) * HW + x0 + p) * kC + 4 * h;
         float psum[3][16];
-        if (RES) load_res(cur, 0, 0, 0);          // (earlier, under the last MFMAs, it costs registers that spill)
+        if (RES) {
+#pragma unroll
+            for (int k = 1; k < 6; ++k) load_res(cur, k);
+        }
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
             for (int nt = 0; nt < 3; ++nt) {
                 const int k = mt * 3 + nt;
-                if (RES && k + 1 < 6) load_res(cur, (k + 1) / 3, (k + 1) % 3, (k + 1) & 1);
                 f32x16& c = acc[mt][nt];
 #pragma unroll
                 for (int G = 0; G < 4; ++G) {
@@ -338,7 +347,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32s_kernel(Conv3x3Args a, int
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.f ? v[e] : v[e] * s4[e];
                     }
-                    if (RES) v += rres[k & 1][G];
+                    if (RES) v += rres[k][G];
                     if (POOL) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) psum[nt][4 * G + e] = mt == 0 ? v[e] : psum[nt][4 * G + e] + v[e];
@@ -379,6 +388,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32s_kernel(Conv3x3Args a, int
         if (!has_next) break;
         item = nxt;
         cur = nx;
+    }
+    if (ABL & 256) {
+        if (tid == 0 && blockIdx.x == 0) ((long long*)a.zeros)[0] = clock64() - t_start;
     }
 }
 

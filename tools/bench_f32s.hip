@@ -20,7 +20,7 @@ static int run(const char* name, Conv3x3Args a, int reps)
     hipEvent_t e0, e1;
     CK_(hipEventCreate(&e0));
     CK_(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < 10; ++i)
         hipLaunchKernelGGL((conv3x3_f32s_kernel<64, false, false, RES, ABL>), dim3(grid), dim3(256), LDS_BYTES, 0, a, nitems);
     CK_(hipDeviceSynchronize());
     CK_(hipEventRecord(e0, 0));
@@ -31,7 +31,11 @@ static int run(const char* name, Conv3x3Args a, int reps)
     CK_(hipGetLastError());
     float ms = 0;
     CK_(hipEventElapsedTime(&ms, e0, e1));
-    printf("%-44s %8.1f us\n", name, ms / reps * 1e3);
+    long long clk = 0;
+    if (a.zeros) CK_(hipMemcpy(&clk, a.zeros, 8, hipMemcpyDeviceToHost));
+    printf("%-44s %8.1f us", name, ms / reps * 1e3);
+    if ((ABL & 256) && a.zeros) printf("   workgroup 0: %lld cycles -> %.2f GHz", clk, clk / (ms / reps * 1e3) * 1e-3);
+    printf("\n");
     fflush(stdout);
     return 0;
 }
@@ -58,18 +62,27 @@ int main(int argc, char** argv)
     Conv3x3Args a{};
     a.in = x; a.out = y; a.wpack = w; a.bias = b; a.slope = sl; a.res = nullptr; a.pool_partial = nullptr;
     a.N = N; a.H = 64; a.W = 64; a.cout_blocks = 1; a.shuffle = 0;
+    void* clk;
+    CK_(hipMalloc(&clk, 64));
+    a.zeros = clk;
     Conv3x3Args ar = a;
     ar.res = r;
-    if (run<0, false>("full", a, reps)) return 1;
-    if (run<0, true>("full + residual", ar, reps)) return 1;
-    if (run<1, false>("no store_a (split + LDS write of pixels)", a, reps)) return 1;
-    if (run<3, false>("no store_a, no chunk-end barrier", a, reps)) return 1;
-    if (run<4, false>("no MFMA", a, reps)) return 1;
-    if (run<8, false>("no fragment LDS reads", a, reps)) return 1;
-    if (run<16, false>("no global loads", a, reps)) return 1;
-    if (run<16 + 32 + 1, false>("no global loads, no LDS stores", a, reps)) return 1;
-    if (run<64 + 2, false>("no barriers", a, reps)) return 1;
-    if (run<8 + 16 + 32 + 1, false>("MFMA + barriers only", a, reps)) return 1;
-    if (run<8 + 16 + 32 + 1 + 64 + 2, false>("MFMA only", a, reps)) return 1;
+    if (argc > 2) {                                   // counter passes (rocprofv3 --pmc): the library's kernels, few launches
+        if (run<0, false>("full", a, 2)) return 1;
+        if (run<0, true>("full + residual", ar, 2)) return 1;
+        return 0;
+    }
+    for (int round = 0; round < 3; ++round) {
+        printf("-- round %d\n", round);
+        if (run<256, false>("full", a, reps)) return 1;
+        if (run<256, true>("full + residual", ar, reps)) return 1;
+        if (run<256 + 1, false>("no pixel staging (load, split, LDS write)", a, reps)) return 1;
+        if (run<256 + 4, false>("no MFMA", a, reps)) return 1;
+        if (run<256 + 8, false>("no fragment LDS reads", a, reps)) return 1;
+        if (run<256 + 16, false>("no global loads", a, reps)) return 1;
+        if (run<256 + 64 + 2, false>("no barriers", a, reps)) return 1;
+        if (run<256 + 8 + 16 + 1, false>("MFMA + barriers only", a, reps)) return 1;
+        if (run<256 + 8 + 16 + 1 + 64 + 2, false>("MFMA only", a, reps)) return 1;
+    }
     return 0;
 }
