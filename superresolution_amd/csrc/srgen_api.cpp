@@ -341,6 +341,28 @@ std::vector<uint16_t> pack_head_bf16(const Folded& f)
     return p;
 }
 
+// split head: 8-half units [g 6][ky 9][hi | lo][lane 64]; lane = 32 h + n, ci = 16 g + 8 h + e, n = kx*3 + co (< 27)
+std::vector<uint16_t> pack_head_split_f16(const Folded& f)
+{
+    std::vector<uint16_t> p((size_t)6 * 9 * 2 * 64 * 8, 0);
+    auto bits = [](_Float16 v) { uint16_t u; memcpy(&u, &v, 2); return u; };
+    for (int g = 0; g < 6; ++g)
+        for (int ky = 0; ky < 9; ++ky)
+            for (int hh = 0; hh < 2; ++hh)
+                for (int kx = 0; kx < 9; ++kx)
+                    for (int co = 0; co < 3; ++co)
+                        for (int e = 0; e < 8; ++e) {
+                            const int ci = 16 * g + 8 * hh + e, lane = 32 * hh + kx * 3 + co;
+                            const float v = f.w[(((size_t)co * 96 + ci) * 9 + ky) * 9 + kx];
+                            const _Float16 hi = (_Float16)v;
+                            const _Float16 lo = (_Float16)(v - (float)hi);
+                            const size_t unit = (((size_t)g * 9 + ky) * 2) * 64 + lane;
+                            p[unit * 8 + e] = bits(hi);
+                            p[(unit + 64) * 8 + e] = bits(lo);
+                        }
+    return p;
+}
+
 std::vector<int> identity_perm(int n)
 {
     std::vector<int> v(n);
@@ -532,6 +554,7 @@ int srgen_commit_weights(srgen_handle* h, void* stream)
         h->head = ConvDev();
         h->head.w_f32 = blob.put_f32(pack_head_f32(f));
         h->head.w_bf16 = blob.put_u16(pack_head_bf16(f));
+        h->head.w_split = blob.put_u16(pack_head_split_f16(f));
         h->head.bias = blob.put_f32(f.b);
     }
 
@@ -750,9 +773,10 @@ static int run_forward(srgen_handle* h, const void* x, void* y, void* workspace,
     HIP_TRY(conv(h->out0, u, v, nullptr, nullptr, kHR, 0));
     HIP_TRY(tap(8, v, kHR * kHR));
     {   // output[2] + crop                                               Generator.py:71, 80
-        HeadArgs a{v, y, B + (bf ? h->head.w_bf16 : h->head.w_f32), F(h->head.bias), n};
+        const bool hsplit = !bf && h->f32_split;
+        HeadArgs a{v, y, B + (bf ? h->head.w_bf16 : hsplit ? h->head.w_split : h->head.w_f32), F(h->head.bias), n};
         HIP_TRY(tick(SRGEN_K_HEAD));
-        HIP_TRY(bf ? launch_head_bf16(a, s) : launch_head_f32(a, s));
+        HIP_TRY(bf ? launch_head_bf16(a, s) : hsplit ? launch_head_f32_split(a, s) : launch_head_f32(a, s));
         HIP_TRY(tock());
     }
     return SRGEN_OK;

@@ -13,4 +13,4 @@ with torch.no_grad():
     y = m(x)
 ref = g["y_dense_sparse"]
 err = float(np.abs(y.cpu().numpy() - ref).max() / np.abs(ref).max())
-print(json.dumps({"path": os.environ.get("SRGEN_F32_CONV3X3", "wino (default)"), "max_rel_err_vs_reference_fp32": err}))
+print(json.dumps({"path": os.environ.get("SRGEN_F32_CONV3X3", "split (default)"), "max_rel_err_vs_reference_fp32": err}))
