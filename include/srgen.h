@@ -195,6 +195,27 @@ SRGEN_API int srgen_wino_pack(const float* w_oihw, int cout_total, int mode, int
 SRGEN_API int srgen_conv3x3_nhwc(const float* x, const float* wpack, const float* bias, const float* res, float* out,
                                  int n, int hw, int cout_blocks, int shuffle, void* stream);
 
+/* The same two operators for the split path (srgen_conv3x3_f32s.hip: fp32 tensors and accumulation, every product from
+ * two-term f16 splits of both operands on the f16 MFMA; the default fp32 path of srgen_forward).  Replaces the same
+ * reference sites: F.conv2d(x, w, b, padding=1) of Generator.py:34,37,62 and its data gradient.
+ * f16 keeps 11 significant bits down to 6.1e-5 only, so both operands are scaled by powers of two into its normal range
+ * before they are split (exact) and the sums scaled back: the weights by their own maximum when the image is packed, the
+ * input by *in_amax.
+ *   srgen_split_pack: modes and `block` as srgen_wino_pack; out: cout_total/96 (mode 0) or 1 (mode 1) images of 331,776
+ *                     bytes, then a 128-byte tail (32 partial maxima of |w|); 16-byte aligned
+ *   srgen_absmax:     out[SRGEN_AMAX_SLOTS] = partial maxima of |x| over numel floats (their maximum is max |x|; what
+ *                     in_amax wants: one launch, nothing to zero; a NaN in x is ignored); out 16-byte aligned
+ *   srgen_conv3x3_nhwc_split: arguments as srgen_conv3x3_nhwc with an image from srgen_split_pack; in_amax:
+ *                     SRGEN_AMAX_SLOTS device floats whose maximum bounds max |x| within a few binades (e.g. from
+ *                     srgen_absmax), or NULL for inputs of order 1
+ *                     (activations): unscaled, inputs below 2^-3 then carry an absolute error of 2^-25, and |x| must
+ *                     stay below the f16 maximum 65,504. */
+#define SRGEN_AMAX_SLOTS 1024
+SRGEN_API int srgen_split_pack(const float* w_oihw, int cout_total, int mode, int block, void* out, void* stream);
+SRGEN_API int srgen_absmax(const float* x, size_t numel, float* out, void* stream);
+SRGEN_API int srgen_conv3x3_nhwc_split(const float* x, const void* wpack, const float* bias, const float* res, float* out,
+                                       int n, int hw, int cout_blocks, int shuffle, const float* in_amax, void* stream);
+
 /* Replaces: the weight / bias gradient of F.conv2d(x, w, b, padding=1): dw (96, 96, 3, 3) OIHW =
  * sum over pixels dy[n,y,x,co] * x[n,y+ky-1,x+kx-1,ci]; dbias [96] = sum dy (NULL to skip).  Fixed summation order. */
 SRGEN_API int srgen_conv3x3_wgrad_scratch_bytes(int n, int hw, size_t* bytes);

@@ -213,8 +213,11 @@ std::vector<float> pack3x3_f32(const Folded& f, int cb, const std::vector<int>& 
 // ci = 16 chunk + 8 (l >> 5) + e -- the MFMA A fragment of v_mfma_f32_32x32x16_f16.
 std::vector<uint16_t> pack3x3_split_f16(const Folded& f, int cb, const std::vector<int>& perm)
 {
-    std::vector<uint16_t> p((size_t)cb * 18 * 1152 * 8);
+    std::vector<uint16_t> p((size_t)cb * 18 * 1152 * 8 + kSplitTailBytes / 2, 0);
     auto bits = [](_Float16 v) { uint16_t u; memcpy(&u, &v, 2); return u; };
+    float amax = 0.f;
+    for (float v : f.w) amax = std::max(amax, std::fabs(v));
+    const float sc = pow2f(split_exp(amax));           // weights scaled into f16's normal range (srgen_internal.h)
     for (int b = 0; b < cb; ++b)
         for (int ch = 0; ch < 6; ++ch)
             for (int ky = 0; ky < 3; ++ky)
@@ -224,13 +227,14 @@ std::vector<uint16_t> pack3x3_split_f16(const Folded& f, int cb, const std::vect
                             for (int e = 0; e < 8; ++e) {
                                 const int oc = perm[b * 96 + 32 * nt + (lane & 31)];
                                 const int ci = 16 * ch + 8 * (lane >> 5) + e;
-                                const float v = f.w[(((size_t)oc * 96 + ci) * 3 + ky) * 3 + kx];
+                                const float v = f.w[(((size_t)oc * 96 + ci) * 3 + ky) * 3 + kx] * sc;
                                 const _Float16 hi = (_Float16)v;
                                 const _Float16 lo = (_Float16)(v - (float)hi);
                                 const size_t unit = ((((((size_t)b * 6 + ch) * 3 + ky) * 3 + kx) * 3 + nt) * 2) * 64 + lane;
                                 p[unit * 8 + e] = bits(hi);
                                 p[(unit + 64) * 8 + e] = bits(lo);
                             }
+    memcpy(&p[(size_t)cb * 18 * 1152 * 8], &amax, 4);   // tail: the kernel derives the same exponent from it
     return p;
 }
 
@@ -344,8 +348,12 @@ std::vector<uint16_t> pack_head_bf16(const Folded& f)
 // split head: 8-half units [g 6][ky 9][hi | lo][lane 64]; lane = 32 h + n, ci = 16 g + 8 h + e, n = kx*3 + co (< 27)
 std::vector<uint16_t> pack_head_split_f16(const Folded& f)
 {
-    std::vector<uint16_t> p((size_t)6 * 9 * 2 * 64 * 8, 0);
+    const size_t body = (size_t)6 * 9 * 2 * 64 * 8;
+    std::vector<uint16_t> p(body + kSplitTailBytes / 2, 0);
     auto bits = [](_Float16 v) { uint16_t u; memcpy(&u, &v, 2); return u; };
+    float amax = 0.f;
+    for (float v : f.w) amax = std::max(amax, std::fabs(v));
+    const float sc = pow2f(split_exp(amax));
     for (int g = 0; g < 6; ++g)
         for (int ky = 0; ky < 9; ++ky)
             for (int hh = 0; hh < 2; ++hh)
@@ -353,13 +361,14 @@ std::vector<uint16_t> pack_head_split_f16(const Folded& f)
                     for (int co = 0; co < 3; ++co)
                         for (int e = 0; e < 8; ++e) {
                             const int ci = 16 * g + 8 * hh + e, lane = 32 * hh + kx * 3 + co;
-                            const float v = f.w[(((size_t)co * 96 + ci) * 9 + ky) * 9 + kx];
+                            const float v = f.w[(((size_t)co * 96 + ci) * 9 + ky) * 9 + kx] * sc;
                             const _Float16 hi = (_Float16)v;
                             const _Float16 lo = (_Float16)(v - (float)hi);
                             const size_t unit = (((size_t)g * 9 + ky) * 2) * 64 + lane;
                             p[unit * 8 + e] = bits(hi);
                             p[(unit + 64) * 8 + e] = bits(lo);
                         }
+    memcpy(&p[body], &amax, 4);
     return p;
 }
 
@@ -594,7 +603,8 @@ static int prepare_train(srgen_handle* h, hipStream_t s)
     auto raw = [&](const std::string& key) {
         Folded f = fold(h, key, "", 1.0, 96, 96, 3);             // no BatchNorm folded in, scale 1
         ConvDev d;
-        d.w_wino = blob.put_f32(pack3x3_wino_f32(f, 1, id96));
+        if (h->f32_split) d.w_split = blob.put_u16(pack3x3_split_f16(f, 1, id96));
+        else d.w_wino = blob.put_f32(pack3x3_wino_f32(f, 1, id96));
         d.bias = blob.put_f32(f.b);
         return d;
     };
@@ -705,14 +715,14 @@ static int run_forward(srgen_handle* h, const void* x, void* y, void* workspace,
                        float res_factor) -> int {
         Conv3x3Args a;
         a.in = in; a.out = out;
-        a.wpack = TB + d.w_wino;
+        a.wpack = TB + (h->f32_split ? d.w_split : d.w_wino);
         a.zeros = B + h->zeros;
         a.bias = (const float*)(TB + d.bias);
         a.slope = (const float*)(TB + h->t_ones);                // identity PReLU: the raw conv output
         a.res = nullptr; a.pool_partial = nullptr;
         a.N = n; a.H = kLR; a.W = kLR;
         a.cout_blocks = 1; a.shuffle = 0;
-        HIP_TRY(launch_conv3x3_f32_wino(a, s));
+        HIP_TRY(h->f32_split ? launch_conv3x3_f32_split(a, s) : launch_conv3x3_f32_wino(a, s));
         const float* gb = (const float*)(TB + h->t_affine) + (size_t)bn_index * 192;
         HIP_TRY(launch_bn_train((float*)out, (size_t)n * kLR * kLR, gb, gb + 96, slope, (const float*)res,
                                 res_factor, W + ws.bn, bn_stats + (size_t)bn_index * 192, s));

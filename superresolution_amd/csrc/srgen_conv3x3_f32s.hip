@@ -29,6 +29,8 @@
 namespace srgen {
 namespace c3s {
 
+static_assert(kAmaxSlots == 4 * 256, "one float4 of partial maxima per thread");
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -106,6 +108,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32s_kernel(Conv3x3Args a, int
     float* const ldsSlope = ldsBias + 4 * 96;
     float* const ldsPool = (float*)(lds + POOL_OFF);
 
+    // ---- power-of-two scaling of both operands into f16's normal range (srgen_internal.h: split_exp) --------------
+    // weights: scaled when the image was packed, by the exponent of the amax in the image's tail; input: scaled
+    // at the split by the exponent of *in_amax (gradients; nullptr = activations of order 1, left alone).  The
+    // accumulators then hold 2^(kw + kx) times the conv: the bias goes in scaled up, the result comes out scaled down.
+    const int kw = split_tail_exp((const char*)a.wpack + (size_t)CB * kSplitImageBytes, lane);
+    int kx = 0;
+    if (a.in_amax) {                                  // maximum of the kAmaxSlots partial maxima
+        const f32x4 q = *(const f32x4*)(a.in_amax + tid * 4);
+        float m = fmaxf(fmaxf(q.x, q.y), fmaxf(q.z, q.w));
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if (lane == 0) ldsPool[w] = m;
+        __syncthreads();
+        kx = split_exp(fmaxf(fmaxf(ldsPool[0], ldsPool[1]), fmaxf(ldsPool[2], ldsPool[3])));
+        __syncthreads();
+    }
+    const float in_mul = pow2f(kx), acc_mul = pow2f(kw + kx), out_mul = pow2f(-(kw + kx));
+
     // ---- halo tile staging: fp32 pieces -> registers -> split (under the MFMAs) -> LDS ----------------------------
     // Per item every thread keeps the image-relative offsets of its seven 16-byte pieces (clamped into the image) and a
     // validity bit each; a chunk's load is then seven loads at offset + 16 c.
@@ -137,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32s_kernel(Conv3x3Args a, int
         const bool ok = (aok >> it) & 1u;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float v = ok ? stage[it][e] : 0.f;
+            const float v = ok ? stage[it][e] * in_mul : 0.f;
             chi[it][e] = (_Float16)v;
             clo[it][e] = (_Float16)(v - (float)chi[it][e]);
         }
@@ -194,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32s_kernel(Conv3x3Args a, int
     load_a(cur, 0);
     issue_w(cur.cb, 0, 0);
     for (int i = tid; i < CB * 96; i += 256) {
-        ldsBias[i] = a.bias[i];
+        ldsBias[i] = a.bias[i] * acc_mul;
         ldsSlope[i] = act ? a.slope[i] : 1.f;
     }
 #pragma unroll
@@ -342,6 +362,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32s_kernel(Conv3x3Args a, int
 #pragma unroll
                 for (int G = 0; G < 4; ++G) {
                     f32x4 v = {c[4 * G], c[4 * G + 1], c[4 * G + 2], c[4 * G + 3]};
+                    v *= out_mul;
                     if (act) {
                         const f32x4 s4 = *(const f32x4*)(ldsSlope + cur.cb * 96 + 32 * nt + 8 * G + 4 * h);
 #pragma unroll

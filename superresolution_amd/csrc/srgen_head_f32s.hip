@@ -48,7 +48,9 @@ __global__ __launch_bounds__(NTHR, 1) void head_f32s_kernel(HeadArgs a)
     const int ty = blk % (kHR / 4), n = blk / (kHR / 4);
     const int y0 = ty * 4;
     const float* in = (const float*)a.in + (size_t)n * kHR * kHR * kC;
-    const h8* wp = (const h8*)a.wpack;                // units [chunk 6][ky 9][hi|lo][lane 64]
+    const h8* wp = (const h8*)a.wpack;                // units [chunk 6][ky 9][hi|lo][lane 64], then the amax tail
+    // the weights were scaled by 2^kw when the image was packed (srgen_internal.h: split_exp)
+    const float out_mul = pow2f(-split_tail_exp((const char*)a.wpack + (size_t)6 * 9 * 2 * 64 * 16, lane));
 
     f32x16 acc[2];
 #pragma unroll
@@ -167,13 +169,13 @@ __global__ __launch_bounds__(NTHR, 1) void head_f32s_kernel(HeadArgs a)
         // the two waves of a row split its 3 x 125 outputs
         for (int i = lane + 64 * mh; i < 3 * kOut; i += 128) {
             const int co = i / kOut, x = i - co * kOut;
-            float s = a.bias[co];
+            float s = 0.f;
 #pragma unroll
             for (int kx = 0; kx < 9; ++kx) {
                 const int xs = x + kx - 4;            // x' of this tap; outside the image T is zero
                 if ((unsigned)xs < (unsigned)COLS) s += Tl[xs * TS + kx * 3 + co];
             }
-            yo[((size_t)co * kOut + y) * kOut + x] = s;
+            yo[((size_t)co * kOut + y) * kOut + x] = a.bias[co] + s * out_mul;
         }
     }
 }

@@ -45,7 +45,38 @@ struct Conv3x3Args {
     int shuffle;           // 1: PixelShuffle(2) store (cout block b -> sub-pixel (b>>1, b&1))
     const void* zeros = nullptr;   // kWinoZeroBytes zero bytes in device memory (Winograd kernel: source
                                    // of out-of-image halo rows for global_load_lds), else unused
+    const float* in_amax = nullptr;   // split kernel only: kAmaxSlots device floats whose maximum is >= max |in| (any
+                                      // bound within a few binades): the input is scaled by a power of two into f16's
+                                      // range before it is split.  nullptr: no scaling (activations of order 1)
 };
+
+// ---- split path (f16 two-term splits): power-of-two scaling into f16's normal range ---------------------------
+// x = hi + lo is good to 2^-22 |x| only while lo is a normal f16 number, i.e. |x| >= 2^-3; below that the error is the
+// f16 subnormal spacing 2^-25, absolute.  Weights (order 1e-2) and gradients (order 1e-6) are therefore multiplied by
+// 2^k with amax * 2^k in [2^13, 2^14) before the split (exact in fp32) and the sums by 2^-k after: the absolute error
+// floor becomes 2^-38 amax.  The weight image carries its amax in a tail of 32 partial maxima (kSplitTailBytes).
+constexpr size_t kSplitImageBytes = (size_t)18 * 1152 * 16;     // one 96 -> 96 cout block
+constexpr size_t kSplitTailBytes = 128;                         // 32 floats whose maximum is max |w|
+constexpr int kAmaxSlots = 1024;                                // partial maxima an in_amax argument points at
+__host__ __device__ inline int split_exp(float amax)
+{
+    const unsigned u = __builtin_bit_cast(unsigned, amax);
+    const int e = (int)((u >> 23) & 255u);
+    if (e == 0 || e == 255) return 0;                  // zero, subnormal, inf, nan: leave the tensor as it is
+    const int k = 13 - (e - 127);
+    return k < -60 ? -60 : (k > 60 ? 60 : k);
+}
+__host__ __device__ inline float pow2f(int k) { return __builtin_bit_cast(float, (unsigned)(k + 127) << 23); }
+#ifdef __HIPCC__
+// exponent for a weight image: every lane of the wave returns split_exp(max of the 32 tail floats)
+__device__ inline int split_tail_exp(const void* tail, int lane)
+{
+    float m = lane < 32 ? ((const float*)tail)[lane] : 0.f;
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    return split_exp(__shfl(m, 0));
+}
+#endif
 
 // ---- 9x9 stem, NCHW 3ch in -> NHWC 96 out, bias + PReLU ---------------------------------
 struct StemArgs {
@@ -188,6 +219,10 @@ hipError_t launch_bn_train(float* t, size_t npix, const float* gamma, const floa
 // Winograd weight image formed on the device from OIHW fp32 weights: mode 0 forward (cout_total 96 or 384, the
 // latter with the PixelShuffle channel permutation), mode 1 data gradient of cout block `block`
 hipError_t launch_wino_pack(const float* w, float* out, int cout_total, int mode, int block, hipStream_t s);
+// the same for the split-f16 kernel: out = kSplitImageBytes per cout block + kSplitTailBytes
+hipError_t launch_split_pack(const float* w, void* out, int cout_total, int mode, int block, hipStream_t s);
+// out[kAmaxSlots] = per-workgroup maxima of |x| (their maximum is max |x|)
+hipError_t launch_absmax(const float* x, size_t n, float* out, hipStream_t s);
 size_t conv3x3_wgrad_scratch_bytes(int n, int h);
 // dw: (96, 96, 3, 3) OIHW; dbias: [96] or nullptr; x, dy: (n, h, h, 96) NHWC
 hipError_t launch_conv3x3_wgrad(const float* x, const float* dy, int n, int h, float* dw, float* dbias, void* scratch,

@@ -75,8 +75,41 @@ int srgen_wino_pack(const float* w_oihw, int cout_total, int mode, int block, fl
     return SRGEN_OK;
 }
 
+int srgen_split_pack(const float* w_oihw, int cout_total, int mode, int block, void* out, void* stream)
+{
+    if (!w_oihw || !out) return fail(SRGEN_E_INVALID, "NULL argument");
+    if (cout_total != 96 && cout_total != 384) return fail(SRGEN_E_UNSUPPORTED, "cout %d: 96 or 384", cout_total);
+    if (mode != 0 && mode != 1) return fail(SRGEN_E_INVALID, "mode %d: 0 forward, 1 data gradient", mode);
+    if (block < 0 || block >= cout_total / 96) return fail(SRGEN_E_INVALID, "block %d outside [0, %d)", block, cout_total / 96);
+    HIP_TRY(launch_split_pack(w_oihw, out, cout_total, mode, block, (hipStream_t)stream));
+    return SRGEN_OK;
+}
+
+static int conv3x3_nhwc_any(const float* x, const void* wpack, const float* bias, const float* res, float* out, int n, int hw,
+                            int cout_blocks, int shuffle, void* stream, bool split, const float* in_amax);
+
+int srgen_absmax(const float* x, size_t numel, float* out, void* stream)
+{
+    if (!x || !out || !numel) return fail(SRGEN_E_INVALID, "NULL or empty argument");
+    if (!aligned16(out)) return fail(SRGEN_E_INVALID, "out must be 16-byte aligned");
+    HIP_TRY(launch_absmax(x, numel, out, (hipStream_t)stream));
+    return SRGEN_OK;
+}
+
 int srgen_conv3x3_nhwc(const float* x, const float* wpack, const float* bias, const float* res, float* out, int n, int hw,
                        int cout_blocks, int shuffle, void* stream)
+{
+    return conv3x3_nhwc_any(x, wpack, bias, res, out, n, hw, cout_blocks, shuffle, stream, false, nullptr);
+}
+
+int srgen_conv3x3_nhwc_split(const float* x, const void* wpack, const float* bias, const float* res, float* out, int n, int hw,
+                             int cout_blocks, int shuffle, const float* in_amax, void* stream)
+{
+    return conv3x3_nhwc_any(x, wpack, bias, res, out, n, hw, cout_blocks, shuffle, stream, true, in_amax);
+}
+
+static int conv3x3_nhwc_any(const float* x, const void* wpack, const float* bias, const float* res, float* out, int n, int hw,
+                            int cout_blocks, int shuffle, void* stream, bool split, const float* in_amax)
 {
     if (!x || !wpack || !out) return fail(SRGEN_E_INVALID, "NULL argument");
     if (n <= 0) return fail(SRGEN_E_INVALID, "batch %d", n);
@@ -94,8 +127,10 @@ int srgen_conv3x3_nhwc(const float* x, const float* wpack, const float* bias, co
     a.bias = bias ? bias : (const float*)consts;                          // bias-free: the zero page
     a.slope = res ? nullptr : (const float*)(consts + kOnesOff);          // identity PReLU = the raw conv output
     a.res = res; a.pool_partial = nullptr;
+    if (in_amax && !aligned16(in_amax)) return fail(SRGEN_E_INVALID, "in_amax must be 16-byte aligned");
+    a.in_amax = in_amax;
     a.N = n; a.H = hw; a.W = hw; a.cout_blocks = cout_blocks; a.shuffle = shuffle;
-    HIP_TRY(launch_conv3x3_f32_wino(a, (hipStream_t)stream));
+    HIP_TRY(split ? launch_conv3x3_f32_split(a, (hipStream_t)stream) : launch_conv3x3_f32_wino(a, (hipStream_t)stream));
     return SRGEN_OK;
 }
 

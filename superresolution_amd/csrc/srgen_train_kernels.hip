@@ -12,6 +12,7 @@
 // transposed, flipped weight image made here.
 #include "srgen_internal.h"
 
+#include <cstdint>
 #include <cstring>
 
 namespace srgen {
@@ -57,6 +58,93 @@ hipError_t launch_wino_pack(const float* w, float* out, int cout_total, int mode
     const int cb = mode == 0 ? cout_total / 96 : 1;
     hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)((cb * 96 * 96 + 255) / 256)), dim3(256), 0, s, w, out, cb, shuffle,
                        mode, block);
+    return hipGetLastError();
+}
+
+// ---- split-f16 weight image on the device (layout of srgen_conv3x3_f32s.hip / srgen_api.cpp pack3x3_split_f16) ----
+// 8-half units [cb][chunk 6][ky 3][kx 3][nt 3][hi | lo][lane 64]; lane l of a unit: co = 32 nt + (l & 31),
+// ci = 16 chunk + 8 (l >> 5) + e; then a tail of 32 partial maxima of |w| over the whole weight, by whose exponent the
+// weights are scaled before the split (srgen_internal.h: split_exp).  Modes as wino_pack_kernel.
+
+// max |x| of a tensor as kAmaxSlots per-workgroup maxima (the split conv kernel reduces them itself: no atomics, nothing
+// to zero, one launch).  NaNs are ignored (fmaxf).
+__device__ __forceinline__ float block_max_256(float m)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    return fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+}
+
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, size_t n4, size_t n, float* out)
+{
+    float m = 0.f;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        const f32x4 v = ((const f32x4*)x)[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    if (blockIdx.x == 0)
+        for (size_t i = n4 * 4 + threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(x[i]));
+    m = block_max_256(m);
+    if (threadIdx.x == 0) out[blockIdx.x] = m;
+}
+
+hipError_t launch_absmax(const float* x, size_t n, float* out, hipStream_t s)
+{
+    const size_t n4 = ((uintptr_t)x & 15) ? 0 : n / 4;
+    hipLaunchKernelGGL(absmax_kernel, dim3(kAmaxSlots), dim3(256), 0, s, x, n4, n, out);
+    return hipGetLastError();
+}
+
+// 32 partial maxima of |w| into the image's tail (its own small launch: 32 workgroups), then the pack
+__global__ __launch_bounds__(256) void weight_absmax_kernel(const float* __restrict__ w, int n, float* tail)
+{
+    float m = 0.f;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += 32 * 256) m = fmaxf(m, fabsf(w[i]));   // (4-byte aligned views)
+    m = block_max_256(m);
+    if (threadIdx.x == 0) tail[blockIdx.x] = m;
+}
+
+__global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict__ w, _Float16* __restrict__ out, int cb,
+                                                         int shuffle, int mode, int block, const float* tail)
+{
+    const float sc = pow2f(split_tail_exp(tail, threadIdx.x & 63));
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= cb * 96 * 96) return;
+    const int ci = idx % 96, co = (idx / 96) % 96, b = idx / (96 * 96);
+    const int lane = (co & 31) + 32 * ((ci >> 3) & 1), e = ci & 7;
+    for (int ky = 0; ky < 3; ++ky)
+        for (int kx = 0; kx < 3; ++kx) {
+            float v;
+            if (mode == 0) {
+                const int oc = shuffle ? 4 * co + b : 96 * b + co;
+                v = w[((size_t)oc * 96 + ci) * 9 + ky * 3 + kx];
+            } else {
+                const int oc = shuffle ? 4 * ci + block : 96 * block + ci;
+                v = w[((size_t)oc * 96 + co) * 9 + (2 - ky) * 3 + (2 - kx)];
+            }
+            v *= sc;
+            const _Float16 hi = (_Float16)v;
+            const _Float16 lo = (_Float16)(v - (float)hi);
+            const size_t unit = ((((((size_t)b * 6 + ci / 16) * 3 + ky) * 3 + kx) * 3 + co / 32) * 2) * 64 + lane;
+            out[unit * 8 + e] = hi;
+            out[(unit + 64) * 8 + e] = lo;
+        }
+}
+
+hipError_t launch_split_pack(const float* w, void* out, int cout_total, int mode, int block, hipStream_t s)
+{
+    const int shuffle = cout_total == 384;
+    const int cb = mode == 0 ? cout_total / 96 : 1;
+    float* tail = (float*)((char*)out + (size_t)cb * kSplitImageBytes);
+    hipLaunchKernelGGL(weight_absmax_kernel, dim3(32), dim3(256), 0, s, w, cout_total * 864, tail);   // whole weight: a bound
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)((cb * 96 * 96 + 255) / 256)), dim3(256), 0, s, w, (_Float16*)out, cb,
+                       shuffle, mode, block, tail);
     return hipGetLastError();
 }
 

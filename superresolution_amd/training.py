@@ -12,6 +12,7 @@ conv to bf16; the fp32 operators here are the stricter computation of the same s
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -19,6 +20,9 @@ import torch
 from . import _lib
 
 WINO_FLOATS = 16 * 96 * 96           # Winograd weight image of one 96 -> 96 conv
+SPLIT_HALFS = 2 * 9 * 96 * 96         # split-f16 weight image of one 96 -> 96 conv: (hi, lo) per weight
+AMAX_SLOTS = 1024                     # SRGEN_AMAX_SLOTS (include/srgen.h)
+SPLIT_TAIL_HALFS = 64                 # ... and its 128-byte tail: 32 partial maxima of |w| (the weights' scale)
 
 
 def _stream(t: torch.Tensor) -> int:
@@ -60,17 +64,69 @@ def wino_pack(w: torch.Tensor, mode: int = 0, block: int = 0) -> torch.Tensor:
     return out
 
 
+def split_pack(w: torch.Tensor, mode: int = 0, block: int = 0) -> torch.Tensor:
+    """Weight image of the split-f16 3x3 kernel (an fp16 tensor: high and low parts of every weight) of a (cout, 96, 3, 3)
+    fp32 weight; modes as ``wino_pack``."""
+    if not w.is_cuda or w.dtype != torch.float32 or w.dim() != 4 or tuple(w.shape[1:]) != (96, 3, 3):
+        raise RuntimeError(f"expected a ROCm fp32 (cout, 96, 3, 3) weight, got {tuple(w.shape)} on {w.device}")
+    wc = w.detach().contiguous()
+    cb = wc.shape[0] // 96 if mode == 0 else 1
+    out = torch.empty(cb * SPLIT_HALFS + SPLIT_TAIL_HALFS, dtype=torch.float16, device=w.device)
+    with torch.cuda.device(w.device):
+        _lib.check(_lib.lib().srgen_split_pack(wc.data_ptr(), wc.shape[0], mode, block, out.data_ptr(), _stream(w)))
+    return out
+
+
+def conv_path() -> str:
+    """The fp32 3x3 kernel the training operators use: ``SRGEN_F32_CONV3X3`` = split (default) | wino (``direct`` has no
+    device-side weight packing: the Winograd kernel stands in for it)."""
+    v = os.environ.get("SRGEN_F32_CONV3X3") or "split"
+    if v not in ("split", "wino", "direct"):
+        raise RuntimeError(f"SRGEN_F32_CONV3X3='{v}': expected split, wino or direct")
+    return "split" if v == "split" else "wino"
+
+
+def conv_pack(w: torch.Tensor, mode: int = 0, block: int = 0) -> torch.Tensor:
+    """The weight image ``conv3x3`` wants for the selected kernel (``conv_path``)."""
+    return split_pack(w, mode, block) if conv_path() == "split" else wino_pack(w, mode, block)
+
+
+def absmax(x: torch.Tensor) -> torch.Tensor:
+    """``AMAX_SLOTS`` partial maxima of |x| on the device (their maximum is max |x|): what the split conv kernel takes
+    as the bound of a gradient input.  One launch, no host synchronisation."""
+    if not x.is_cuda or x.dtype != torch.float32 or not x.is_contiguous():
+        raise RuntimeError("absmax: a contiguous fp32 ROCm tensor; there is no CPU fallback")
+    out = torch.empty(AMAX_SLOTS, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().srgen_absmax(x.data_ptr(), x.numel(), out.data_ptr(), _stream(x)))
+    return out
+
+
 def conv3x3(x: torch.Tensor, wpack: torch.Tensor, bias: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
-            cout_blocks: int = 1, shuffle: bool = False) -> torch.Tensor:
-    """``conv(x) + bias [+ res]`` on NHWC fp32 (``F.conv2d(..., padding=1)``); with a mode-1 image: the data gradient."""
+            cout_blocks: int = 1, shuffle: bool = False, scale_input: bool = False) -> torch.Tensor:
+    """``conv(x) + bias [+ res]`` on NHWC fp32 (``F.conv2d(..., padding=1)``); with a mode-1 image: the data gradient.
+    The image's dtype picks the kernel: fp16 (``split_pack``) the split-f16 one, fp32 (``wino_pack``) Winograd.
+    ``scale_input``: the input is a gradient (any magnitude): the split kernel scales it by a power of two taken from
+    ``absmax(x)`` before it forms the f16 parts (activations of order 1 need none; Winograd ignores the flag)."""
     _chk_nhwc("x", x)
     n, hw = x.shape[0], x.shape[1]
     oh = 2 * hw if shuffle else hw
+    split = wpack.dtype == torch.float16
+    want = cout_blocks * SPLIT_HALFS + SPLIT_TAIL_HALFS if split else cout_blocks * WINO_FLOATS
+    if wpack.numel() != want or not wpack.is_contiguous():
+        raise RuntimeError(f"weight image of {wpack.numel()} {wpack.dtype} values does not fit {cout_blocks} cout block(s)")
     out = torch.empty((n, oh, oh, 96), dtype=torch.float32, device=x.device)
+    pb = bias.data_ptr() if bias is not None else None
+    pr = res.data_ptr() if res is not None else None
     with torch.cuda.device(x.device):
-        _lib.check(_lib.lib().srgen_conv3x3_nhwc(x.data_ptr(), wpack.data_ptr(), bias.data_ptr() if bias is not None else None,
-                                                 res.data_ptr() if res is not None else None, out.data_ptr(), n, hw, cout_blocks,
-                                                 1 if shuffle else 0, _stream(x)))
+        if split:
+            amax = absmax(x) if scale_input else None
+            _lib.check(_lib.lib().srgen_conv3x3_nhwc_split(x.data_ptr(), wpack.data_ptr(), pb, pr, out.data_ptr(), n, hw,
+                                                           cout_blocks, 1 if shuffle else 0,
+                                                           amax.data_ptr() if amax is not None else None, _stream(x)))
+        else:
+            _lib.check(_lib.lib().srgen_conv3x3_nhwc(x.data_ptr(), wpack.data_ptr(), pb, pr, out.data_ptr(), n, hw,
+                                                     cout_blocks, 1 if shuffle else 0, _stream(x)))
     return out
 
 
@@ -225,9 +281,9 @@ def resblock_forward(x: torch.Tensor, block: torch.nn.Module, ws: Workspace):
     (keys ``block.{0,3}.{weight,bias}``, ``block.{1,4}.{weight,bias}``, ``block.2.weight``).  Returns the output and
     what the backward needs: the two raw conv outputs, conv2's input, and the batch statistics."""
     seq = block.block
-    c1 = conv3x3(x, wino_pack(seq[0].weight), seq[0].bias.detach())
+    c1 = conv3x3(x, conv_pack(seq[0].weight), seq[0].bias.detach())
     t, st1 = bn_train_fwd(c1, seq[1].weight.detach(), seq[1].bias.detach(), ws, slope=seq[2].weight.detach())
-    c2 = conv3x3(t, wino_pack(seq[3].weight), seq[3].bias.detach())
+    c2 = conv3x3(t, conv_pack(seq[3].weight), seq[3].bias.detach())
     out, st2 = bn_train_fwd(c2, seq[4].weight.detach(), seq[4].bias.detach(), ws, res=x, res_factor=0.1)
     return out, {"x": x, "c1": c1, "t": t, "c2": c2, "st1": st1, "st2": st2}
 
@@ -243,13 +299,13 @@ def resblock_backward(dout: torch.Tensor, saved: dict, block: torch.nn.Module, w
                                                                    seq[4].bias.detach(), ws, dout_scale=0.1,
                                                                    dgamma=d("block.4.weight"), dbeta=d("block.4.bias"))
     g["block.3.weight"], g["block.3.bias"] = conv3x3_wgrad(saved["t"], dc2, ws, d("block.3.weight"), d("block.3.bias"))
-    dt = conv3x3(dc2, wino_pack(seq[3].weight, mode=1))
+    dt = conv3x3(dc2, conv_pack(seq[3].weight, mode=1), scale_input=True)
     # t = PReLU(bn1(c1))
     dc1, g["block.1.weight"], g["block.1.bias"], g["block.2.weight"] = bn_train_bwd(
         saved["c1"], dt, saved["st1"], seq[1].weight.detach(), seq[1].bias.detach(), ws, slope=seq[2].weight.detach(),
         dgamma=d("block.1.weight"), dbeta=d("block.1.bias"), dslope=d("block.2.weight"))
     g["block.0.weight"], g["block.0.bias"] = conv3x3_wgrad(saved["x"], dc1, ws, d("block.0.weight"), d("block.0.bias"))
-    dx = conv3x3(dc1, wino_pack(seq[0].weight, mode=1), res=dout)          # + the identity branch
+    dx = conv3x3(dc1, conv_pack(seq[0].weight, mode=1), res=dout, scale_input=True)          # + the identity branch
     return dx, g
 
 
@@ -407,15 +463,15 @@ class PretrainStep:
                 cur, saved = chan_attn_forward(cur, m)
             S["blocks"].append(saved)
         S["mid_in"] = cur
-        S["mid_c"] = conv3x3(cur, wino_pack(g.mid[0].weight), g.mid[0].bias.detach())
+        S["mid_c"] = conv3x3(cur, conv_pack(g.mid[0].weight), g.mid[0].bias.detach())
         m_out, S["mid_st"] = bn_train_fwd(S["mid_c"], g.mid[1].weight.detach(), g.mid[1].bias.detach(), ws, res=x1, res_factor=1.0)
         stats.append(S["mid_st"])
         S["m"] = m_out
         up = g.upsample
         bias_p = up.conv.bias.detach().view(96, 4).t().contiguous().view(-1)      # packed block b holds channels 4c + b
-        S["u_pre"] = conv3x3(m_out, wino_pack(up.conv.weight), bias_p, cout_blocks=4, shuffle=True)
+        S["u_pre"] = conv3x3(m_out, conv_pack(up.conv.weight), bias_p, cout_blocks=4, shuffle=True)
         S["u"] = prelu_scalar(S["u_pre"], up.act.weight.detach())
-        S["v_pre"] = conv3x3(S["u"], wino_pack(g.output[0].weight), g.output[0].bias.detach())
+        S["v_pre"] = conv3x3(S["u"], conv_pack(g.output[0].weight), g.output[0].bias.detach())
         S["v"] = prelu_scalar(S["v_pre"], g.output[1].weight.detach())
         y = head_forward(S["v"], g.output[2].weight, g.output[2].bias)
         S["stats"] = stats
@@ -439,7 +495,7 @@ class PretrainStep:
         dv_pre, ds = prelu_scalar_bwd(S["v_pre"], dv, g.output[1].weight.detach(), ws)
         put("output.1.weight", ds)
         conv3x3_wgrad(S["u"], dv_pre, ws, P["output.0.weight"].grad, P["output.0.bias"].grad)
-        du = conv3x3(dv_pre, wino_pack(g.output[0].weight, mode=1))
+        du = conv3x3(dv_pre, conv_pack(g.output[0].weight, mode=1), scale_input=True)
         # upsample: conv 96 -> 384, PixelShuffle(2), scalar PReLU (Generator.py:4-12)
         up = g.upsample
         du_pre, ds = prelu_scalar_bwd(S["u_pre"], du, up.act.weight.detach(), ws)
@@ -453,12 +509,12 @@ class PretrainStep:
             dw, db = conv3x3_wgrad(S["m"], pl, ws)
             gw[:, b].copy_(dw)
             gb[:, b].copy_(db)
-            dm = conv3x3(pl, wino_pack(up.conv.weight, mode=1, block=b), res=dm)
+            dm = conv3x3(pl, conv_pack(up.conv.weight, mode=1, block=b), res=dm, scale_input=True)
         # mid conv + BatchNorm, long skip x1 + x3 (Generator.py:61-64,78)
         dc, _, _, _ = bn_train_bwd(S["mid_c"], dm, S["mid_st"], g.mid[1].weight.detach(), g.mid[1].bias.detach(), ws,
                                    dgamma=P["mid.1.weight"].grad, dbeta=P["mid.1.bias"].grad)
         conv3x3_wgrad(S["mid_in"], dc, ws, P["mid.0.weight"].grad, P["mid.0.bias"].grad)
-        dcur = conv3x3(dc, wino_pack(g.mid[0].weight, mode=1))
+        dcur = conv3x3(dc, conv_pack(g.mid[0].weight, mode=1), scale_input=True)
         # trunk, last module first (Generator.py:55-59)
         for idx in range(len(g.blocks) - 1, -1, -1):
             m, saved = g.blocks[idx], S["blocks"][idx]

@@ -5,6 +5,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #define CK_(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
@@ -47,8 +48,12 @@ int main(int argc, char** argv)
     std::vector<float> hx(act);
     unsigned s = 12345;
     for (auto& v : hx) { s = s * 1664525u + 1013904223u; v = ((s >> 8) & 0xffff) / 65536.f - 0.5f; }
-    std::vector<_Float16> hw((size_t)18 * c3s::WG_UNITS * 8);
+    std::vector<_Float16> hw((size_t)18 * c3s::WG_UNITS * 8 + 64, (_Float16)0.f);
     for (auto& v : hw) { s = s * 1664525u + 1013904223u; v = (_Float16)((((s >> 8) & 0xffff) / 65536.f - 0.5f) * 0.05f); }
+    {                                                 // the image's amax tail: 32 floats
+        float tail[32] = {1.f};
+        memcpy(&hw[(size_t)18 * c3s::WG_UNITS * 8], tail, sizeof tail);
+    }
     std::vector<float> hb(96, 0.01f), hs(96, 0.25f);
     float *x, *y, *r, *b, *sl;
     void* w;

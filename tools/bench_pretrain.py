@@ -22,13 +22,13 @@ def bench_ops(torch, T, dev, batch):
     gamma, beta = torch.rand(96, generator=gen).to(dev) + 0.5, torch.randn(96, generator=gen).to(dev) * 0.1
     slope = torch.full((96,), 0.25, device=dev)
     ws = T.Workspace(dev)
-    wp, wd = T.wino_pack(w, 0), T.wino_pack(w, 1)
+    wp, wd = T.conv_pack(w, 0), T.conv_pack(w, 1)
     _, stats = T.bn_train_fwd(x, gamma, beta, ws, slope=slope)
     ops = {"conv3x3_fwd": lambda: T.conv3x3(x, wp), "conv3x3_dgrad": lambda: T.conv3x3(dy, wd),
            "conv3x3_wgrad": lambda: T.conv3x3_wgrad(x, dy, ws),
            "bn_prelu_fwd": lambda: T.bn_train_fwd(x, gamma, beta, ws, slope=slope),
            "bn_prelu_bwd": lambda: T.bn_train_bwd(x, dy, stats, gamma, beta, ws, slope=slope),
-           "wino_pack": lambda: T.wino_pack(w, 1)}
+           "conv_pack": lambda: T.conv_pack(w, 1)}
     out = {}
     for name, fn in ops.items():
         for _ in range(3):
