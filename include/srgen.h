@@ -227,7 +227,9 @@ SRGEN_API int srgen_conv3x3_wgrad(const float* x, const float* dy, int n, int hw
  *   fwd: out = res + res_factor * PReLU_slope(bn(c))   (slope / res may be NULL; out may alias c);
  *        batch_stats [2][96] = {batch mean, biased batch variance} (the caller applies the running-stat update)
  *   bwd: given dout = d/d(PReLU(bn(c))), scaled by dout_scale (the 0.1 of the residual branch):
- *        dc, dgamma [96], dbeta [96], dslope [96] (iff slope) */
+ *        dc, dgamma [96], dbeta [96], dslope [96] (iff slope); dc_amax: NULL, or SRGEN_AMAX_SLOTS floats that receive
+ *        partial maxima of |dc| (what srgen_conv3x3_nhwc_split takes as in_amax for the data-gradient conv that reads
+ *        dc next: saves the srgen_absmax pass) */
 SRGEN_API int srgen_bn_train_scratch_bytes(size_t* bytes);
 SRGEN_API int srgen_bn_train_fwd(const float* c, float* out, const float* gamma, const float* beta, const float* slope,
                                  const float* res, float res_factor, float* batch_stats, size_t npix, void* scratch,
@@ -235,7 +237,7 @@ SRGEN_API int srgen_bn_train_fwd(const float* c, float* out, const float* gamma,
 SRGEN_API int srgen_bn_train_bwd(const float* c, const float* dout, const float* batch_stats, const float* gamma,
                                  const float* beta, const float* slope, float dout_scale, float* dc, float* dgamma,
                                  float* dbeta, float* dslope, size_t npix, void* scratch, size_t scratch_bytes,
-                                 void* stream);
+                                 float* dc_amax, void* stream);
 
 /* Replaces: nn.PReLU() with ONE slope (Generator.py:51, 9, 70) forward and backward, elementwise over numel floats
  * (a multiple of 4).  slope / dslope: one device float.  y may alias x; dx may alias dy.  dy2 (may be NULL): a second
@@ -266,6 +268,10 @@ SRGEN_API int srgen_conv9x9_c3_wgrad(const float* act, const float* img, int n, 
  * ci = 8 c8 + 2 (2u + h) + e, n = 3 kx + co (27 used) -- superresolution_amd/training.py forms it on the device.
  * y: (n, 3, 125, 125) NCHW. */
 SRGEN_API int srgen_head_nhwc(const float* v, const float* wpack, const float* bias, float* y, int n, void* stream);
+/* The same on the split path (srgen_head_f32s.hip).  wpack: f16 units of 8 [chunk 6][ky 9][hi | lo][lane 64] with lane =
+ * 32 h + n, ci = 16 chunk + 8 h + e, n = 3 kx + co, of the weight times 2^k (k: srgen_internal.h split_exp of max |w|),
+ * then a 128-byte tail whose first float is max |w| -- superresolution_amd/training.py forms it on the device. */
+SRGEN_API int srgen_head_nhwc_split(const float* v, const void* wpack, const float* bias, float* y, int n, void* stream);
 
 /* Replaces: ChannelAttention.forward and its backward (Generator.py:15-27) on an NHWC (n, 64, 64, 96) tensor.
  *   fwd: x is scaled IN PLACE by s = sigmoid(W2 relu(W1 mean_hw(x) + b1) + b2); pool_partial [n][16][96] (channel sums of

@@ -91,7 +91,7 @@ def lib() -> ctypes.CDLL:
     L.srgen_conv3x3_wgrad.argtypes = [vp, vp, i, i, vp, vp, vp, sz, vp]
     L.srgen_bn_train_scratch_bytes.argtypes = [ctypes.POINTER(sz)]
     L.srgen_bn_train_fwd.argtypes = [vp, vp, vp, vp, vp, vp, f, vp, sz, vp, sz, vp]
-    L.srgen_bn_train_bwd.argtypes = [vp, vp, vp, vp, vp, vp, f, vp, vp, vp, vp, sz, vp, sz, vp]
+    L.srgen_bn_train_bwd.argtypes = [vp, vp, vp, vp, vp, vp, f, vp, vp, vp, vp, sz, vp, sz, vp, vp]
     L.srgen_pixel_loss_grad.argtypes = [vp, vp, i, i, i, i, f, f, vp, vp, sz, vp]
     L.srgen_adamw.argtypes = [vp, vp, vp, vp, sz, f, f, f, f, f, i, vp]
     L.srgen_prelu_scratch_bytes.argtypes = [ctypes.POINTER(sz)]
@@ -101,6 +101,7 @@ def lib() -> ctypes.CDLL:
     L.srgen_conv9x9_c3_wgrad_scratch_bytes.argtypes = [i, i, ctypes.POINTER(sz)]
     L.srgen_conv9x9_c3_wgrad.argtypes = [vp, vp, i, i, i, i, i, i, vp, vp, vp, sz, vp]
     L.srgen_head_nhwc.argtypes = [vp, vp, vp, vp, i, vp]
+    L.srgen_head_nhwc_split.argtypes = [vp, vp, vp, vp, i, vp]
     L.srgen_chan_attn_nhwc.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, vp]
     L.srgen_chan_attn_bwd_scratch_bytes.argtypes = [i, ctypes.POINTER(sz)]
     L.srgen_chan_attn_bwd.argtypes = [vp, vp, vp, vp, i, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
@@ -126,7 +127,7 @@ def lib() -> ctypes.CDLL:
                  "srgen_clip_grad_norm"):
         getattr(L, name).restype = i
     for name in ("srgen_prelu_scratch_bytes", "srgen_prelu_scalar_fwd", "srgen_prelu_scalar_bwd", "srgen_conv9x9_c3_nhwc",
-                 "srgen_conv9x9_c3_wgrad_scratch_bytes", "srgen_conv9x9_c3_wgrad", "srgen_head_nhwc", "srgen_chan_attn_nhwc",
+                 "srgen_conv9x9_c3_wgrad_scratch_bytes", "srgen_conv9x9_c3_wgrad", "srgen_head_nhwc", "srgen_head_nhwc_split", "srgen_chan_attn_nhwc",
                  "srgen_chan_attn_bwd_scratch_bytes", "srgen_chan_attn_bwd"):
         getattr(L, name).restype = i
     for name in ("srgen_wino_pack", "srgen_conv3x3_nhwc", "srgen_split_pack", "srgen_conv3x3_nhwc_split", "srgen_absmax", "srgen_conv3x3_wgrad_scratch_bytes", "srgen_conv3x3_wgrad",

@@ -231,7 +231,7 @@ size_t bn_bwd_scratch_bytes();
 // c: saved conv output; dt: gradient of the BatchNorm(+PReLU) output (scaled by dscale); stats: {mean, biased var}
 hipError_t launch_bn_train_bwd(const float* c, const float* dt, const float* stats, const float* gamma, const float* beta,
                                const float* slope, float dscale, float* dc, float* dgamma, float* dbeta, float* dslope,
-                               size_t npix, void* scratch, hipStream_t s);
+                               size_t npix, void* scratch, hipStream_t s, float* dc_amax = nullptr);
 // dsr = d/dsr [w_l1 * weighted_l1(sr, hr) + w_ssim * (1 - ssim(sr, hr))]; scratch: 3 * n*c*h*w floats
 hipError_t launch_pixel_loss_grad(const float* sr, const float* hr, int n, int c, int h, int w, float w_l1, float w_ssim,
                                   float* dsr, void* scratch, hipStream_t s);

@@ -174,7 +174,7 @@ int srgen_bn_train_fwd(const float* c, float* out, const float* gamma, const flo
 
 int srgen_bn_train_bwd(const float* c, const float* dout, const float* batch_stats, const float* gamma, const float* beta,
                        const float* slope, float dout_scale, float* dc, float* dgamma, float* dbeta, float* dslope,
-                       size_t npix, void* scratch, size_t scratch_bytes, void* stream)
+                       size_t npix, void* scratch, size_t scratch_bytes, float* dc_amax, void* stream)
 {
     if (!c || !dout || !batch_stats || !gamma || !beta || !dc || !dgamma || !dbeta || !scratch)
         return fail(SRGEN_E_INVALID, "NULL argument");
@@ -183,7 +183,7 @@ int srgen_bn_train_bwd(const float* c, const float* dout, const float* batch_sta
     if (scratch_bytes < bn_bwd_scratch_bytes()) return fail(SRGEN_E_WORKSPACE, "BatchNorm scratch too small");
     if (!aligned16(c) || !aligned16(dout) || !aligned16(dc)) return fail(SRGEN_E_INVALID, "operands must be 16-byte aligned");
     HIP_TRY(launch_bn_train_bwd(c, dout, batch_stats, gamma, beta, slope, dout_scale, dc, dgamma, dbeta, slope ? dslope : nullptr,
-                                npix, scratch, (hipStream_t)stream));
+                                npix, scratch, (hipStream_t)stream, dc_amax));
     return SRGEN_OK;
 }
 
@@ -270,6 +270,16 @@ int srgen_head_nhwc(const float* v, const float* wpack, const float* bias, float
     if (n <= 0) return fail(SRGEN_E_INVALID, "batch %d", n);
     HeadArgs a{v, y, wpack, bias, n};
     HIP_TRY(launch_head_f32(a, (hipStream_t)stream));
+    return SRGEN_OK;
+}
+
+int srgen_head_nhwc_split(const float* v, const void* wpack, const float* bias, float* y, int n, void* stream)
+{
+    if (!v || !wpack || !bias || !y) return fail(SRGEN_E_INVALID, "NULL argument");
+    if (n <= 0) return fail(SRGEN_E_INVALID, "batch %d", n);
+    if (!aligned16(v) || !aligned16(wpack)) return fail(SRGEN_E_INVALID, "operands must be 16-byte aligned");
+    HeadArgs a{v, y, wpack, bias, n};
+    HIP_TRY(launch_head_f32_split(a, (hipStream_t)stream));
     return SRGEN_OK;
 }
 

@@ -693,8 +693,9 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* __restri
 // Block b owns channels [12b, 12b+12): 36 sums x 28 threads, each adding every 28th partial (fixed order).
 __global__ __launch_bounds__(1024) void bn_bwd_final_kernel(const double* partial, int nb, double npix,
                                                             const float* stats, const float* gamma, const float* beta, float* coef,
-                                                            float* dgamma, float* dbeta, float* dslope)
+                                                            float* dgamma, float* dbeta, float* dslope, float* amax)
 {
+    if (amax && blockIdx.x == 0) amax[threadIdx.x] = 0.f;       // kAmaxSlots = 1024 = this workgroup (see bn_bwd_apply_kernel)
     __shared__ double part[28][36];
     __shared__ double tot[36];
     const int t = threadIdx.x;
@@ -739,9 +740,10 @@ __global__ __launch_bounds__(1024) void bn_bwd_final_kernel(const double* partia
 // grid * 256 is a multiple of 24, so a thread meets the same four channels at every stride: constants in registers
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ c, const float* __restrict__ dt,
                                                            const float* __restrict__ slope, const float* __restrict__ coef,
-                                                           float dscale, float* __restrict__ dc, size_t n4)
+                                                           float dscale, float* __restrict__ dc, size_t n4, float* amax)
 {
     const size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    float m = 0.f;
     const int ch = (int)(i0 % 24) * 4;
     float A[4], B[4], C[4], P[4], Q[4], S[4];
 #pragma unroll
@@ -759,8 +761,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
             const float z = fmaf(cv[e], P[e], Q[e]);
             const float dz = (slope && z < 0.f) ? dv[e] * S[e] : dv[e];
             o[e] = fmaf(A[e], dz, -C[e]) - B[e] * cv[e];
+            m = fmaxf(m, fabsf(o[e]));
         }
         *(f32x4*)(dc + i * 4) = o;
+    }
+    // max |dc| for the split-f16 data-gradient conv that reads dc next (its in_amax): slot = workgroup mod kAmaxSlots,
+    // zeroed by bn_bwd_final_kernel; non-negative floats order like their bit patterns
+    if (amax) {
+        m = block_max_256(m);
+        if (threadIdx.x == 0 && m == m) atomicMax((unsigned*)amax + (blockIdx.x & (kAmaxSlots - 1)), __float_as_uint(m));
     }
 }
 
@@ -768,19 +777,20 @@ size_t bn_bwd_scratch_bytes() { return (size_t)BNB_BLOCKS * 288 * sizeof(double)
 
 hipError_t launch_bn_train_bwd(const float* c, const float* dt, const float* stats, const float* gamma, const float* beta,
                                const float* slope, float dscale, float* dc, float* dgamma, float* dbeta, float* dslope,
-                               size_t npix, void* scratch, hipStream_t s)
+                               size_t npix, void* scratch, hipStream_t s, float* dc_amax)
 {
+    static_assert(kAmaxSlots == 1024, "bn_bwd_final_kernel zeroes one slot per thread");
     double* partial = (double*)scratch;
     float* coef = (float*)(partial + (size_t)BNB_BLOCKS * 288);
     const int nb = npix < (size_t)BNB_BLOCKS * 10 ? (int)((npix + 9) / 10) : BNB_BLOCKS;
     hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(nb), dim3(256), 0, s, c, dt, stats, gamma, beta, slope, dscale, npix, partial);
     hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(8), dim3(1024), 0, s, partial, nb, (double)npix, stats, gamma, beta, coef, dgamma,
-                       dbeta, dslope);
+                       dbeta, dslope, dc_amax);
     const size_t n4 = npix * 24;
     size_t want = (n4 + 255) / 256;
     if (want > 6144) want = 6144;
     want = (want + 2) / 3 * 3;                                   // (grid * 256) % 24 == 0
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)want), dim3(256), 0, s, c, dt, slope, coef, dscale, dc, n4);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)want), dim3(256), 0, s, c, dt, slope, coef, dscale, dc, n4, dc_amax);
     return hipGetLastError();
 }
 

@@ -120,7 +120,11 @@ def conv3x3(x: torch.Tensor, wpack: torch.Tensor, bias: Optional[torch.Tensor] =
     pr = res.data_ptr() if res is not None else None
     with torch.cuda.device(x.device):
         if split:
-            amax = absmax(x) if scale_input else None
+            amax = None
+            if scale_input:                                       # the producer's partial maxima, or a pass of our own
+                amax = getattr(x, "amax_slots", None)
+                if amax is None:
+                    amax = absmax(x)
             _lib.check(_lib.lib().srgen_conv3x3_nhwc_split(x.data_ptr(), wpack.data_ptr(), pb, pr, out.data_ptr(), n, hw,
                                                            cout_blocks, 1 if shuffle else 0,
                                                            amax.data_ptr() if amax is not None else None, _stream(x)))
@@ -190,12 +194,18 @@ def bn_train_bwd(c, dout, stats, gamma, beta, ws: Workspace, slope=None, dout_sc
     dgamma, dbeta = _out(dgamma, (96,), dev), _out(dbeta, (96,), dev)
     dslope = _out(dslope, (96,), dev) if slope is not None else None
     scratch = _bn_scratch(ws)
+    # the split-f16 data-gradient conv that reads dc next wants a bound of |dc| (conv3x3: scale_input): the apply kernel
+    # leaves its partial maxima here, carried on the tensor as ``dc.amax_slots``
+    amax = torch.empty(AMAX_SLOTS, dtype=torch.float32, device=dev) if conv_path() == "split" else None
     with torch.cuda.device(dev):
         _lib.check(_lib.lib().srgen_bn_train_bwd(c.data_ptr(), dout.data_ptr(), stats.data_ptr(), gamma.data_ptr(),
                                                  beta.data_ptr(), slope.data_ptr() if slope is not None else None,
                                                  float(dout_scale), dc.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
                                                  dslope.data_ptr() if dslope is not None else None, c.numel() // 96,
-                                                 scratch.data_ptr(), scratch.numel(), _stream(c)))
+                                                 scratch.data_ptr(), scratch.numel(),
+                                                 amax.data_ptr() if amax is not None else None, _stream(c)))
+    if amax is not None:
+        dc.amax_slots = amax
     return dc, dgamma, dbeta, dslope
 
 
@@ -372,14 +382,37 @@ def head_pack(w: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def head_pack_split(w: torch.Tensor) -> torch.Tensor:
+    """Weight image of the split-path head kernel (srgen_head_f32s.hip) from the (3, 96, 9, 9) weight, on the device:
+    f16 units of 8 [chunk 6][ky 9][hi | lo][lane 64], lane = 32 h + n, ci = 16 chunk + 8 h + e, n = 3 kx + co, of
+    w * 2^k with max |w| * 2^k in [2^13, 2^14) (split_exp of srgen_internal.h: frexp gives the same exponent), then the
+    128-byte tail whose first float is max |w|."""
+    wd = w.detach()
+    amax = wd.abs().max()
+    _, e = torch.frexp(amax)                                  # amax = m * 2^e, m in [0.5, 1): floor(log2 amax) = e - 1
+    k = torch.where(amax > 0, 13 - (e - 1), torch.zeros_like(e)).clamp(-60, 60)
+    ws = torch.ldexp(wd, k)
+    hi = ws.to(torch.float16)
+    lo = (ws - hi.to(torch.float32)).to(torch.float16)
+    img = torch.zeros((6, 9, 2, 2, 32, 8), dtype=torch.float16, device=w.device)         # chunk, ky, hl, h, n, e
+    for hl, part in enumerate((hi, lo)):
+        t = part.permute(2, 1, 3, 0).reshape(9, 6, 2, 8, 27)                              # ky, chunk, h, e, (kx, co)
+        img[:, :, hl, :, :27, :] = t.permute(1, 0, 2, 4, 3)                               # chunk, ky, h, n, e
+    tail = torch.zeros(32, dtype=torch.float32, device=w.device)
+    tail[0] = amax
+    return torch.cat([img.reshape(-1), tail.view(torch.float16)])
+
+
 def head_forward(v: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """``F.conv2d(v, w, b, padding=4)[:, :, :125, :125]`` (Generator.py:71,80): NHWC (n, 128, 128, 96) -> NCHW (n, 3, 125, 125)."""
     _chk_nhwc("v", v)
     n = v.shape[0]
     y = torch.empty((n, 3, 125, 125), dtype=torch.float32, device=v.device)
-    pack = head_pack(w)
+    split = conv_path() == "split"
+    pack = head_pack_split(w) if split else head_pack(w)
+    fn = _lib.lib().srgen_head_nhwc_split if split else _lib.lib().srgen_head_nhwc
     with torch.cuda.device(v.device):
-        _lib.check(_lib.lib().srgen_head_nhwc(v.data_ptr(), pack.data_ptr(), b.detach().data_ptr(), y.data_ptr(), n, _stream(v)))
+        _lib.check(fn(v.data_ptr(), pack.data_ptr(), b.detach().data_ptr(), y.data_ptr(), n, _stream(v)))
     return y
 
 

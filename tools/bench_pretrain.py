@@ -99,7 +99,7 @@ def main():
                       "phases_ms": {"forward": round(ph[0], 3), "loss+grad": round(ph[1], 3), "backward": round(ph[2], 3),
                                     "adamw": round(ph[3], 3)},
                       "algorithmic_tflops": round(flop / (med * 1e-3) / 1e12, 1),
-                      "note": "fp32; conv arithmetic on the Winograd / MFMA kernels; the reference runs this step under bf16 autocast"}))
+                      "note": "fp32 tensors; forward and data-gradient convs on the split-f16 kernel (SRGEN_F32_CONV3X3), weight gradients in the Winograd domain on the fp32 MFMA; the reference runs this step under bf16 autocast"}))
 
 
 if __name__ == "__main__":
