@@ -33,7 +33,8 @@ def pmc_means(d):
 
 def is_trunk(name, dt):
     # the 33 trunk launches: conv3x3_<dt>_kernel<64, false(shuffle), pool?, res?>
-    return f"conv3x3_{dt}_kernel<64, false" in name or f"conv3x3_{dt}_wino_kernel<64, false" in name
+    return (f"conv3x3_{dt}_kernel<64, false" in name or f"conv3x3_{dt}_wino_kernel<64, false" in name
+            or (dt == "f32" and "conv3x3_f32s_kernel<64, false" in name))
 
 
 def main():
@@ -66,7 +67,11 @@ def main():
         if n_f and n_w:
             rd = 2.0 * 1024.0 * fetch / n_f        # KB -> B, gfx950 FETCH_SIZE correction x2
             wr = 1024.0 * write / n_w
-            out = {"conv3x3_trunk_hbm_bytes_per_launch": round(rd + wr),
+            path = dt
+            if dt == "f32":
+                path = ("split" if any("conv3x3_f32s_kernel" in k for k in merged) else
+                        "wino" if any("wino_kernel" in k for k in merged) else "direct")
+            out = {"path": path, "conv3x3_trunk_hbm_bytes_per_launch": round(rd + wr),
                    "read_bytes": round(rd), "write_bytes": round(wr), "launches_sampled": int(n_f),
                    "batch": 256,
                    "source": f"profiles/{tag}_{dt}_pmc.json: FETCH_SIZE (KB, x2 gfx950 correction for 16 B/lane "
