@@ -407,7 +407,7 @@ struct Prof {
 };
 
 struct Workspace {
-    size_t x1, a, b, t, u, v, pool, scale[2], bn, total;
+    size_t x1, a, b, t, u, v, pool, scale[2], bn, amax[3], total;
 };
 
 Workspace plan_workspace(int n, int dtype)
@@ -426,6 +426,7 @@ Workspace plan_workspace(int n, int dtype)
     w.scale[0] = off; off += align256((size_t)n * kC * 4);
     w.scale[1] = off; off += align256((size_t)n * kC * 4);
     w.bn = off; off += align256(bn_scratch_bytes());
+    for (int i = 0; i < 3; ++i) { w.amax[i] = off; off += align256((size_t)n * 4); }
     w.total = off;
     return w;
 }
@@ -682,11 +683,24 @@ static int run_forward(srgen_handle* h, const void* x, void* y, void* workspace,
         if (!prof) return hipSuccess;
         return hipEventRecord(prof->ev[2 * prof->count++ + 1], s);
     };
+    // split path, eval forward: every 3x3 conv (and the head) reads the output of the launch before it, so the bound of
+    // max |activation| by which an image is scaled into f16's range travels down the chain in three rotating arrays of
+    // one float per image: launch L reads S[L % 3] (left by launch L - 1; the stem's output gets an absmax pass), its
+    // waves accumulate the maxima of what they store into S[(L + 1) % 3] (atomic max) and it zeroes S[(L + 2) % 3] for
+    // launch L + 1 to accumulate into.  Per image, so an image's result does not depend on what else is in the batch.
+    // (ChannelAttention scales in place by a sigmoid: the bound stays a bound.)
+    const bool train = bn_stats != nullptr;             // (train mode: tensors behind batch-statistics BatchNorms, no chain)
+    int chain = 0;
+    auto S = [&](int i) { return (float*)(W + ws.amax[i % 3]); };
     auto conv = [&](const ConvDev& d, const void* in, void* out, const void* res, float* pool, int H,
                     int shuffle) -> hipError_t {
         Conv3x3Args a;
         a.in = in; a.out = out;
         const bool wino = !bf && h->f32_wino, split = !bf && h->f32_split;
+        if (split && !train && !getenv("SRGEN_SPLIT_NO_AMAX")) {
+            a.in_amax = S(chain); a.in_amax_per_image = 1; a.out_amax = S(chain + 1); a.zero_amax = S(chain + 2);
+            ++chain;
+        }
         a.wpack = B + (bf ? d.w_bf16 : split ? d.w_split : wino ? d.w_wino : d.w_f32);
         a.zeros = B + h->zeros;
         a.bias = F(d.bias);
@@ -707,7 +721,6 @@ static int run_forward(srgen_handle* h, const void* x, void* y, void* workspace,
     void* t = W + ws.t;
     float* pool = (float*)(W + ws.pool);
 
-    const bool train = bn_stats != nullptr;
     const char* TB = h->tblob;
     int bn_index = 0;
     // conv (unfolded weights, bias, no activation) -> batch statistics -> normalise in place (+ PReLU | + residual)
@@ -736,6 +749,9 @@ static int run_forward(srgen_handle* h, const void* x, void* y, void* workspace,
         HIP_TRY(bf ? launch_stem_bf16(a, s) : launch_stem_f32(a, s));
         HIP_TRY(tock());
         HIP_TRY(tap(0, x1, kLR * kLR));
+        if (!bf && h->f32_split && !train) {
+            HIP_TRY(launch_absmax_per_image((const float*)x1, n, (size_t)kLR * kLR * kC, S(0), S(1), s));
+        }
     }
     const void* cur = x1;                               // x2 = blocks(x1)  Generator.py:76
     int flip = 0;
@@ -785,6 +801,7 @@ static int run_forward(srgen_handle* h, const void* x, void* y, void* workspace,
     {   // output[2] + crop                                               Generator.py:71, 80
         const bool hsplit = !bf && h->f32_split;
         HeadArgs a{v, y, B + (bf ? h->head.w_bf16 : hsplit ? h->head.w_split : h->head.w_f32), F(h->head.bias), n};
+        if (hsplit && !train && !getenv("SRGEN_SPLIT_NO_AMAX")) a.in_amax = S(chain);
         HIP_TRY(tick(SRGEN_K_HEAD));
         HIP_TRY(bf ? launch_head_bf16(a, s) : hsplit ? launch_head_f32_split(a, s) : launch_head_f32(a, s));
         HIP_TRY(tock());

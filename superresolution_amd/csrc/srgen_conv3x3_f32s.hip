@@ -109,22 +109,32 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32s_kernel(Conv3x3Args a, int
     float* const ldsPool = (float*)(lds + POOL_OFF);
 
     // ---- power-of-two scaling of both operands into f16's normal range (srgen_internal.h: split_exp) --------------
-    // weights: scaled when the image was packed, by the exponent of the amax in the image's tail; input: scaled
-    // at the split by the exponent of *in_amax (gradients; nullptr = activations of order 1, left alone).  The
-    // accumulators then hold 2^(kw + kx) times the conv: the bias goes in scaled up, the result comes out scaled down.
+    // weights: scaled by 2^kw when the image was packed (the exponent of the amax in the image's tail); input: scaled by
+    // 2^kx at the split, kx from a bound of max |in|: one for the whole tensor (training gradients: kAmaxSlots partial
+    // maxima, reduced here once), one per image (eval forward: what the producing conv's waves left for that image by
+    // atomic max, read whenever the workgroup moves to an item), or none (in_amax = nullptr: activations of
+    // order 1).  The accumulators then hold 2^(kw + kx) times the conv: the bias goes in scaled up, the result comes
+    // out scaled down.
     const int kw = split_tail_exp((const char*)a.wpack + (size_t)CB * kSplitImageBytes, lane);
-    int kx = 0;
-    if (a.in_amax) {                                  // maximum of the kAmaxSlots partial maxima
+    int kx_all = 0;
+    if (a.in_amax && a.in_amax_per_image == 0) {      // maximum of the kAmaxSlots partial maxima
         const f32x4 q = *(const f32x4*)(a.in_amax + tid * 4);
         float m = fmaxf(fmaxf(q.x, q.y), fmaxf(q.z, q.w));
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
         if (lane == 0) ldsPool[w] = m;
         __syncthreads();
-        kx = split_exp(fmaxf(fmaxf(ldsPool[0], ldsPool[1]), fmaxf(ldsPool[2], ldsPool[3])));
+        kx_all = __builtin_amdgcn_readfirstlane(split_exp(fmaxf(fmaxf(ldsPool[0], ldsPool[1]), fmaxf(ldsPool[2], ldsPool[3]))));
         __syncthreads();
     }
-    const float in_mul = pow2f(kx), acc_mul = pow2f(kw + kx), out_mul = pow2f(-(kw + kx));
+    if (a.zero_amax && blockIdx.x == 0)
+        for (int i = tid; i < a.N; i += 256) a.zero_amax[i] = 0.f;
+    auto item_kx = [&](int n) {                       // wave-uniform: one scalar-cached load
+        if (!a.in_amax || a.in_amax_per_image == 0) return kx_all;
+        return __builtin_amdgcn_readfirstlane(split_exp(a.in_amax[n]));
+    };
+    int kx_stage = 0;                                 // of the item whose pixels are being staged (scalar register)
+    float vmax = 0.f;                                 // max |stored value| of this lane in the current item (-> out_amax)
 
     // ---- halo tile staging: fp32 pieces -> registers -> split (under the MFMAs) -> LDS ----------------------------
     // Per item every thread keeps the image-relative offsets of its seven 16-byte pieces (clamped into the image) and a
@@ -155,6 +165,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32s_kernel(Conv3x3Args a, int
     };
     auto convert_a = [&](int it) {
         const bool ok = (aok >> it) & 1u;
+        const float in_mul = pow2f(kx_stage);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float v = ok ? stage[it][e] * in_mul : 0.f;
@@ -210,11 +221,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32s_kernel(Conv3x3Args a, int
     long long t_start = 0;
     if (ABL & 256) t_start = clock64();
     Item cur = decode(item);
+    int kx_cur = item_kx(cur.n), kx_nx = kx_cur;
+    kx_stage = kx_cur;
     plan_a(cur);
     load_a(cur, 0);
     issue_w(cur.cb, 0, 0);
     for (int i = tid; i < CB * 96; i += 256) {
-        ldsBias[i] = a.bias[i] * acc_mul;
+        ldsBias[i] = a.bias[i];
         ldsSlope[i] = act ? a.slope[i] : 1.f;
     }
 #pragma unroll
@@ -232,14 +245,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32s_kernel(Conv3x3Args a, int
         const int nxt = item + wg_per_xcd;
         const bool has_next = nxt < item_end;
         const Item nx = decode(has_next ? nxt : item);
+        // the next item's bound: loaded here, first looked at five chunks later (no wait on its latency)
+        const bool per_image = a.in_amax && a.in_amax_per_image;
+        const float amax_nx = per_image ? a.in_amax[nx.n] : 0.f;
 
-        // accumulators start at the bias (broadcast LDS reads: the address depends on h only)
+        // accumulators start at the (scaled) bias (broadcast LDS reads: the address depends on h only)
+        const float acc_mul = pow2f(kw + kx_cur), out_mul = pow2f(-(kw + kx_cur));
+        vmax = 0.f;
         f32x16 acc[2][3];
 #pragma unroll
         for (int nt = 0; nt < 3; ++nt)
 #pragma unroll
             for (int G = 0; G < 4; ++G) {
-                const f32x4 b4 = *(const f32x4*)(ldsBias + cur.cb * 96 + 32 * nt + 8 * G + 4 * h);
+                const f32x4 b4 = *(const f32x4*)(ldsBias + cur.cb * 96 + 32 * nt + 8 * G + 4 * h) * acc_mul;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[0][nt][4 * G + e] = acc[1][nt][4 * G + e] = b4[e];
             }
@@ -273,7 +291,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32s_kernel(Conv3x3Args a, int
                     else issue_w(nx.cb, 0, slot ^ 1);
                     if (ky == 0) {
                         if (c + 1 < NCH) load_a(cur, c + 1);
-                        else {
+                        else {                        // the next item's first chunk: its image's scale from here on
+                            kx_nx = per_image ? __builtin_amdgcn_readfirstlane(split_exp(amax_nx)) : kx_all;
+                            kx_stage = kx_nx;
                             plan_a(nx);
                             load_a(nx, 0);
                         }
@@ -369,6 +389,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32s_kernel(Conv3x3Args a, int
                         for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.f ? v[e] : v[e] * s4[e];
                     }
                     if (RES) v += rres[k][G];
+                    vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
                     if (POOL) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) psum[nt][4 * G + e] = mt == 0 ? v[e] : psum[nt][4 * G + e] + v[e];
@@ -406,9 +427,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32s_kernel(Conv3x3Args a, int
             }
             __syncthreads();                      // P is read before the next tile overwrites it
         }
+        if (a.out_amax) {                             // one atomic per wave and item: non-negative floats order like
+#pragma unroll                                        // their bit patterns
+            for (int o = 32; o >= 1; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+            if (lane == 0 && vmax == vmax) atomicMax((unsigned*)a.out_amax + cur.n, __float_as_uint(vmax));
+        }
         if (!has_next) break;
         item = nxt;
         cur = nx;
+        kx_cur = kx_nx;
     }
     if (ABL & 256) {
         if (tid == 0 && blockIdx.x == 0) ((long long*)a.zeros)[0] = clock64() - t_start;

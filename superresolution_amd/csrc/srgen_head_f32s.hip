@@ -20,6 +20,7 @@
 namespace srgen {
 namespace hfs {
 
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -50,7 +51,10 @@ __global__ __launch_bounds__(NTHR, 1) void head_f32s_kernel(HeadArgs a)
     const float* in = (const float*)a.in + (size_t)n * kHR * kHR * kC;
     const h8* wp = (const h8*)a.wpack;                // units [chunk 6][ky 9][hi|lo][lane 64], then the amax tail
     // the weights were scaled by 2^kw when the image was packed (srgen_internal.h: split_exp)
-    const float out_mul = pow2f(-split_tail_exp((const char*)a.wpack + (size_t)6 * 9 * 2 * 64 * 16, lane));
+    const int kw = split_tail_exp((const char*)a.wpack + (size_t)6 * 9 * 2 * 64 * 16, lane);
+    // ... and the input is scaled by 2^kx from the bound its producer left (in_amax: one bound per image)
+    const int kx = a.in_amax ? __builtin_amdgcn_readfirstlane(split_exp(a.in_amax[n])) : 0;
+    const float in_mul = pow2f(kx), out_mul = pow2f(-(kw + kx));
 
     f32x16 acc[2];
 #pragma unroll
@@ -76,7 +80,7 @@ __global__ __launch_bounds__(NTHR, 1) void head_f32s_kernel(HeadArgs a)
         const bool ok = row_ok(it);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float v = ok ? stage[it][e] : 0.f;
+            const float v = ok ? stage[it][e] * in_mul : 0.f;
             chi[it][e] = (_Float16)v;
             clo[it][e] = (_Float16)(v - (float)chi[it][e]);
         }

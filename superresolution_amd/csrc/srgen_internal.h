@@ -45,6 +45,13 @@ struct Conv3x3Args {
     int shuffle;           // 1: PixelShuffle(2) store (cout block b -> sub-pixel (b>>1, b&1))
     const void* zeros = nullptr;   // kWinoZeroBytes zero bytes in device memory (Winograd kernel: source
                                    // of out-of-image halo rows for global_load_lds), else unused
+    float* out_amax = nullptr;        // split kernel only: [N] device floats, zero on entry: max |out| per image (atomic
+                                      // max over the waves that store parts of the image) -- the next conv's in_amax
+    float* zero_amax = nullptr;       // split kernel only: [N] device floats this launch sets to zero (what the launch
+                                      // after the next accumulates into)
+    int in_amax_per_image = 0;        // 0: in_amax is ONE bound for the whole tensor (kAmaxSlots partial maxima: training
+                                      // gradients); 1: in_amax is [N], one bound per image, and every image is scaled
+                                      // by its own (eval forward: an image's result does not depend on its batch)
     const float* in_amax = nullptr;   // split kernel only: kAmaxSlots device floats whose maximum is >= max |in| (any
                                       // bound within a few binades): the input is scaled by a power of two into f16's
                                       // range before it is split.  nullptr: no scaling (activations of order 1)
@@ -57,7 +64,7 @@ struct Conv3x3Args {
 // floor becomes 2^-38 amax.  The weight image carries its amax in a tail of 32 partial maxima (kSplitTailBytes).
 constexpr size_t kSplitImageBytes = (size_t)18 * 1152 * 16;     // one 96 -> 96 cout block
 constexpr size_t kSplitTailBytes = 128;                         // 32 floats whose maximum is max |w|
-constexpr int kAmaxSlots = 1024;                                // partial maxima an in_amax argument points at
+constexpr int kAmaxSlots = 1024;                                // partial maxima a whole-tensor in_amax points at
 __host__ __device__ inline int split_exp(float amax)
 {
     const unsigned u = __builtin_bit_cast(unsigned, amax);
@@ -109,6 +116,7 @@ struct HeadArgs {
     const void* wpack;
     const float* bias;     // [3]
     int N;
+    const float* in_amax = nullptr;   // split head only: [N] bounds of max |in| per image (as Conv3x3Args, per image)
 };
 
 // fp32 kernels (srgen_kernels_f32.hip)
@@ -223,6 +231,8 @@ hipError_t launch_wino_pack(const float* w, float* out, int cout_total, int mode
 hipError_t launch_split_pack(const float* w, void* out, int cout_total, int mode, int block, hipStream_t s);
 // out[kAmaxSlots] = per-workgroup maxima of |x| (their maximum is max |x|)
 hipError_t launch_absmax(const float* x, size_t n, float* out, hipStream_t s);
+// out[i] = max |x[i]| per image (per_image floats each, a multiple of 4), zero_out[i] = 0
+hipError_t launch_absmax_per_image(const float* x, int n, size_t per_image, float* out, float* zero_out, hipStream_t s);
 size_t conv3x3_wgrad_scratch_bytes(int n, int h);
 // dw: (96, 96, 3, 3) OIHW; dbias: [96] or nullptr; x, dy: (n, h, h, 96) NHWC
 hipError_t launch_conv3x3_wgrad(const float* x, const float* dy, int n, int h, float* dw, float* dbias, void* scratch,

@@ -92,6 +92,35 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
     if (threadIdx.x == 0) out[blockIdx.x] = m;
 }
 
+// per image: one workgroup of 1024 threads each; out[i] = max |x[i]|, zero_out[i] = 0
+__global__ __launch_bounds__(1024) void absmax_per_image_kernel(const float* __restrict__ x, size_t per_image, float* out,
+                                                                float* zero_out)
+{
+    const f32x4* src = (const f32x4*)(x + (size_t)blockIdx.x * per_image);
+    float m = 0.f;
+    for (size_t i = threadIdx.x; i < per_image / 4; i += 1024) {
+        const f32x4 v = src[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    __shared__ float part[16];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 16; ++i) m = fmaxf(m, part[i]);
+        out[blockIdx.x] = m;
+        zero_out[blockIdx.x] = 0.f;
+    }
+}
+
+hipError_t launch_absmax_per_image(const float* x, int n, size_t per_image, float* out, float* zero_out, hipStream_t s)
+{
+    if (per_image % 4 || ((uintptr_t)x & 15)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(absmax_per_image_kernel, dim3((unsigned)n), dim3(1024), 0, s, x, per_image, out, zero_out);
+    return hipGetLastError();
+}
+
 hipError_t launch_absmax(const float* x, size_t n, float* out, hipStream_t s)
 {
     const size_t n4 = ((uintptr_t)x & 15) ? 0 : n / 4;

@@ -60,6 +60,37 @@ def test_fp32_vs_cpu_oracle_other_seed(synth_sd_np):
     assert max_rel(y, ref) <= FP32_TOL
 
 
+def test_split_path_scales_tiny_activations_per_image(monkeypatch):
+    """The default fp32 path forms its products from f16 pieces, and f16 keeps 11 bits only down to 6e-5: every image is
+    therefore scaled by a power of two taken from the maximum its producer left for it (srgen_api.cpp: the amax chain).
+    A network without additive terms (conv biases, BatchNorm shifts and means zero: positively homogeneous up to the
+    channel attention) fed an image 2^-20 times the usual size has activations of order 1e-6 throughout; one image of
+    the batch is tiny, its neighbour is not.  Both must meet the fp32 bar against the fp64 C oracle -- and with the
+    chain switched off (SRGEN_SPLIT_NO_AMAX, a test switch) the tiny one must not, which is what the chain is for."""
+    from oracle import oracle as O
+    from superresolution_amd import Generator, weights as W
+    sd_np = W.synthetic_state_dict_numpy(3)
+    for k, v in sd_np.items():
+        if (k.endswith(".bias") or k.endswith(".running_mean")) and ".fc." not in k:
+            v[...] = 0
+    g = Generator()
+    g.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd_np.items()})
+    g = g.cuda().eval()
+    x = W.synthetic_lr_batch(2, seed=9, kind="dense")
+    x[1] *= np.float32(2.0 ** -20)
+    ref = O.generator_forward(sd_np, x)
+    assert np.abs(ref[1]).max() < 1e-3 * np.abs(ref[0]).max()          # the second image really is tiny end to end
+    y = g(torch.from_numpy(x).cuda()).cpu().numpy()
+    errs = [max_rel(y[i:i + 1], ref[i:i + 1]) for i in range(2)]
+    print("with per-image scaling:", errs)
+    assert max(errs) <= FP32_TOL
+    monkeypatch.setenv("SRGEN_SPLIT_NO_AMAX", "1")
+    y0 = g(torch.from_numpy(x).cuda()).cpu().numpy()
+    errs0 = [max_rel(y0[i:i + 1], ref[i:i + 1]) for i in range(2)]
+    print("without:", errs0)
+    assert errs0[0] <= FP32_TOL and errs0[1] > FP32_TOL
+
+
 @pytest.mark.parametrize("path", ["direct", "wino"])
 def test_fp32_exact_mfma_conv_kernels_match_golden_and_the_default(gen, golden, golden_inputs, monkeypatch, path):
     """The fp32 3x3 convs run the split-f16 kernel by default (fp32 tensors and accumulation, every product formed
