@@ -221,6 +221,11 @@ SRGEN_API int srgen_conv3x3_nhwc_split(const float* x, const void* wpack, const 
 SRGEN_API int srgen_conv3x3_wgrad_scratch_bytes(int n, int hw, size_t* bytes);
 SRGEN_API int srgen_conv3x3_wgrad(const float* x, const float* dy, int n, int hw, float* dw, float* dbias,
                                   void* scratch, size_t scratch_bytes, void* stream);
+/* The same gradient on the split arithmetic (srgen_wgrad_f32s.hip; hw a multiple of 64; same scratch size).  dy_amax:
+ * SRGEN_AMAX_SLOTS device floats whose maximum bounds max |dy| (srgen_absmax / the dc_amax of srgen_bn_train_bwd), or
+ * NULL for a dy of order 1: gradients are scaled by a power of two into f16's range before they are split. */
+SRGEN_API int srgen_conv3x3_wgrad_split(const float* x, const float* dy, int n, int hw, const float* dy_amax, float* dw,
+                                        float* dbias, void* scratch, size_t scratch_bytes, void* stream);
 
 /* Replaces: nn.BatchNorm2d(96) in train mode (+ PReLU(96), + the residual add) forward and backward
  * (Generator.py:35-36,38,42).  c: conv output (npix, 96), kept for the backward.

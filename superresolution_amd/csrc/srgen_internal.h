@@ -237,6 +237,13 @@ size_t conv3x3_wgrad_scratch_bytes(int n, int h);
 // dw: (96, 96, 3, 3) OIHW; dbias: [96] or nullptr; x, dy: (n, h, h, 96) NHWC
 hipError_t launch_conv3x3_wgrad(const float* x, const float* dy, int n, int h, float* dw, float* dbias, void* scratch,
                                 hipStream_t s);
+// the same on the split arithmetic (srgen_wgrad_f32s.hip; h a multiple of 64); dy_amax: kAmaxSlots partial maxima of |dy|
+// or nullptr (dy of order 1); scratch of conv3x3_wgrad_scratch_bytes
+hipError_t launch_conv3x3_wgrad_split(const float* x, const float* dy, int n, int h, const float* dy_amax, float* dw,
+                                      float* dbias, void* scratch, hipStream_t s);
+size_t conv3x3_wgrad_split_scratch_bytes(int n, int h);
+hipError_t launch_conv3x3_wgrad_split_partial(const float* x, const float* dy, int n, int h, const float* dy_amax,
+                                              float* slab, float* bias_slab, int* slices_out, hipStream_t s);
 size_t bn_bwd_scratch_bytes();
 // c: saved conv output; dt: gradient of the BatchNorm(+PReLU) output (scaled by dscale); stats: {mean, biased var}
 hipError_t launch_bn_train_bwd(const float* c, const float* dt, const float* stats, const float* gamma, const float* beta,

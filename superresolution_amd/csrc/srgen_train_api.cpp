@@ -151,6 +151,18 @@ int srgen_conv3x3_wgrad(const float* x, const float* dy, int n, int hw, float* d
     return SRGEN_OK;
 }
 
+int srgen_conv3x3_wgrad_split(const float* x, const float* dy, int n, int hw, const float* dy_amax, float* dw, float* dbias,
+                              void* scratch, size_t scratch_bytes, void* stream)
+{
+    if (!x || !dy || !dw || !scratch) return fail(SRGEN_E_INVALID, "NULL argument");
+    if (n <= 0 || hw <= 0 || (hw & 63)) return fail(SRGEN_E_INVALID, "bad shape (n %d, hw %d: a multiple of 64)", n, hw);
+    if (scratch_bytes < conv3x3_wgrad_scratch_bytes(n, hw)) return fail(SRGEN_E_WORKSPACE, "wgrad scratch too small");
+    if (!aligned16(x) || !aligned16(dy) || (dy_amax && !aligned16(dy_amax)))
+        return fail(SRGEN_E_INVALID, "operands must be 16-byte aligned");
+    HIP_TRY(launch_conv3x3_wgrad_split(x, dy, n, hw, dy_amax, dw, dbias, scratch, (hipStream_t)stream));
+    return SRGEN_OK;
+}
+
 int srgen_bn_train_scratch_bytes(size_t* bytes)
 {
     if (!bytes) return fail(SRGEN_E_INVALID, "bytes is NULL");

@@ -601,8 +601,8 @@ static int wgrad_slices(int total_rows)
 
 static bool wgrad_direct()
 {
-    static const bool direct = getenv("SRGEN_WGRAD") && !strcmp(getenv("SRGEN_WGRAD"), "direct");
-    return direct;
+    const char* e = getenv("SRGEN_WGRAD");            // read per call: tests switch it inside one process
+    return e && !strcmp(e, "direct");
 }
 
 static int wgrad_lds_slices(int total_trows)
@@ -617,7 +617,22 @@ size_t conv3x3_wgrad_scratch_bytes(int n, int h)
     const size_t direct = ((size_t)slices * 9 * 9216 + (size_t)slices * 96) * sizeof(float);
     const int ws = wgrad_lds_slices(n * (h / 2));
     const size_t wino = ((size_t)ws + 1) * kWgSliceFloats * sizeof(float);
-    return direct > wino ? direct : wino;
+    const size_t split = (h & 63) ? 0 : conv3x3_wgrad_split_scratch_bytes(n, h);
+    const size_t m = direct > wino ? direct : wino;
+    return m > split ? m : split;
+}
+
+hipError_t launch_conv3x3_wgrad_split(const float* x, const float* dy, int n, int h, const float* dy_amax, float* dw,
+                                      float* dbias, void* scratch, hipStream_t s)
+{
+    int slices = 0;
+    float* slab = (float*)scratch;
+    // (the bias partials sit behind the largest slab the slice count can ask for: 112 slices)
+    float* bias_slab = slab + (size_t)112 * 9 * 9216;
+    hipError_t e = launch_conv3x3_wgrad_split_partial(x, dy, n, h, dy_amax, slab, bias_slab, &slices, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3(9 * 9216 / 64), dim3(256), 0, s, slab, bias_slab, slices, dw, dbias);
+    return hipGetLastError();
 }
 
 hipError_t launch_conv3x3_wgrad(const float* x, const float* dy, int n, int h, float* dw, float* dbias, void* scratch,

@@ -86,6 +86,16 @@ def conv_path() -> str:
     return "split" if v == "split" else "wino"
 
 
+def wgrad_path() -> str:
+    """The 3x3 weight-gradient kernel: ``SRGEN_WGRAD`` = split (default when the convs run the split path: products from
+    f16 splits, srgen_wgrad_f32s.hip) | wino (Winograd domain on the fp32 MFMA) | direct (9-tap GEMM on the fp32 MFMA;
+    read by the library itself)."""
+    v = os.environ.get("SRGEN_WGRAD") or ("split" if conv_path() == "split" else "wino")
+    if v not in ("split", "wino", "direct"):
+        raise RuntimeError(f"SRGEN_WGRAD='{v}': expected split, wino or direct")
+    return v
+
+
 def conv_pack(w: torch.Tensor, mode: int = 0, block: int = 0) -> torch.Tensor:
     """The weight image ``conv3x3`` wants for the selected kernel (``conv_path``)."""
     return split_pack(w, mode, block) if conv_path() == "split" else wino_pack(w, mode, block)
@@ -157,8 +167,16 @@ def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, ws: Workspace, dw: Optional
     dw = _out(dw, (96, 96, 3, 3), x.device)
     db = _out(db, (96,), x.device)
     with torch.cuda.device(x.device):
-        _lib.check(L.srgen_conv3x3_wgrad(x.data_ptr(), dy.data_ptr(), n, hw, dw.data_ptr(), db.data_ptr(), scratch.data_ptr(),
-                                         scratch.numel(), _stream(x)))
+        if wgrad_path() == "split" and hw % 64 == 0:
+            # the split kernel scales the gradient into f16's range: its producer's partial maxima, or a pass of our own
+            amax = getattr(dy, "amax_slots", None)
+            if amax is None:
+                amax = absmax(dy)
+            _lib.check(L.srgen_conv3x3_wgrad_split(x.data_ptr(), dy.data_ptr(), n, hw, amax.data_ptr(), dw.data_ptr(),
+                                                   db.data_ptr(), scratch.data_ptr(), scratch.numel(), _stream(x)))
+        else:
+            _lib.check(L.srgen_conv3x3_wgrad(x.data_ptr(), dy.data_ptr(), n, hw, dw.data_ptr(), db.data_ptr(),
+                                             scratch.data_ptr(), scratch.numel(), _stream(x)))
     return dw, db
 
 

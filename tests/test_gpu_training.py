@@ -138,6 +138,25 @@ def test_conv3x3_dgrad_and_wgrad_at_128(gold, pack):
     assert max_rel(db.cpu().numpy(), br.grad.numpy()) <= TOL
 
 
+@pytest.mark.parametrize("wgrad", ["split", "wino", "direct"])
+@pytest.mark.parametrize("shape,scale", [((3, 96, 64, 64), 1.0), ((2, 96, 128, 128), 2.0 ** -22), ((5, 96, 64, 64), 2.0 ** 9)])
+def test_conv3x3_wgrad_kernels_vs_torch(wgrad, shape, scale, monkeypatch):
+    """The three weight-gradient kernels (SRGEN_WGRAD) against torch's own on the CPU in fp64: ragged batch sizes (slices
+    that end inside an image, empty slices) and gradients far outside f16's range, which the split kernel has to scale."""
+    from superresolution_amd import training as T
+    monkeypatch.setenv("SRGEN_WGRAD", wgrad)
+    x = _hash_tensor(51, "wg.x", shape)
+    gr = _hash_tensor(52, "wg.g", shape) * scale
+    w = torch.zeros(96, 96, 3, 3, dtype=torch.float64, requires_grad=True)
+    b = torch.zeros(96, dtype=torch.float64, requires_grad=True)
+    (F.conv2d(x.double(), w, b, padding=1) * gr.double()).sum().backward()
+    ws = T.Workspace(torch.device("cuda"))
+    dw, db = T.conv3x3_wgrad(_nhwc(x).cuda(), _nhwc(gr).cuda(), ws)
+    ew, eb = max_rel(dw.cpu().double().numpy(), w.grad.numpy()), max_rel(db.cpu().double().numpy(), b.grad.numpy())
+    print(wgrad, shape, scale, "dw", ew, "db", eb)
+    assert ew <= 2e-5 and eb <= 2e-5
+
+
 def test_pixel_loss_grad_vs_reference_golden(gold, golden):
     from superresolution_amd import pixel_losses, training as T, weights as W
     ws = T.Workspace(torch.device("cuda"))
