@@ -185,10 +185,13 @@ def training_leg(args, dev, rank, n_ranks, use_dist):
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    # dominant kernel: the 3x3 weight gradient (43.5 GFLOP algorithmic, 19.3 executed per launch at 64 images), timed
-    # alone with HIP events
+    # dominant kernel: the 3x3 weight gradient (43.5 GFLOP algorithmic per launch at 64 images; the split kernel executes
+    # 3 f16 MFMAs per product, the Winograd-domain kernel 16/36 on the fp32 MFMA), timed alone with HIP events; the
+    # gradient operand carries its partial maxima as in the step (no absmax pass inside the timed op)
     ws = T.Workspace(dev)
     xa = torch.randn((n, 64, 64, 96), device=dev)
+    if T.wgrad_path() == "split":
+        xa.amax_slots = T.absmax(xa)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(21)]
     for _ in range(3):
         T.conv3x3_wgrad(xa, xa, ws)
@@ -199,19 +202,26 @@ def training_leg(args, dev, rank, n_ranks, use_dist):
     ev[-1].synchronize()
     wg_ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(20))[10]
     flop_alg = 2.0 * n * 4096 * 96 * 864
-    flop = flop_alg * WINO_EXECUTED                   # the weight gradient runs in the Winograd domain too: F(3x3, 2x2)
+    wpath = T.wgrad_path()
+    ratio, peak, kname = ((SPLIT_EXECUTED, PEAK["f16"], "wgs::conv3x3_wgrad_split_kernel + conv3x3_wgrad_reduce_kernel") if wpath == "split"
+                          else (WINO_EXECUTED, PEAK["f32"], "conv3x3_wgrad_wino_lds_kernel + sum + final") if wpath == "wino"
+                          else (1.0, PEAK["f32"], "conv3x3_wgrad_kernel + reduce"))
+    flop = flop_alg * ratio
     if rank == 0:
         print(json.dumps({
             "metric": metric, "value": round(n * n_ranks * args.steps / dt, 1), "unit": "images/s", "n_gpus": n_ranks,
             "steps": args.steps, "warmup": max(args.warmup, 3), "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": name, "batch_per_gpu": n, "global_batch": n * n_ranks, "parallelism": f"dp{n_ranks}",
+                       "precision": f"fp32 tensors and accumulation; 3x3 conv products: {T.conv_path()} (forward, data "
+                                    f"gradient), {wpath} (weight gradient) -- split = two-term f16 splits of both "
+                                    "operands, three f16 MFMAs per product, operands range-scaled by powers of two",
                        "collective": "one all-reduce of the flat gradient buffer per optimizer step (12.86 MB generator, "
                                      "23.5 MB discriminator)"},
             "loss_last": float(loss),
-            "roofline": {"bound": "mfma", "kernel": "conv3x3_wgrad_wino_lds_kernel + sum + final (38 launches per generator backward)",
-                         "achieved": round(flop / (wg_ms * 1e-3) / 1e12, 2), "peak": 157.3, "unit": "TFLOP/s",
-                         "frac": round(flop / (wg_ms * 1e-3) / 1e12 / 157.3, 4), "traffic": None,
+            "roofline": {"bound": "mfma", "kernel": kname + " (38 launches per generator backward)",
+                         "achieved": round(flop / (wg_ms * 1e-3) / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(flop / (wg_ms * 1e-3) / 1e12 / peak, 4), "traffic": None,
                          "ms_per_launch": round(wg_ms, 4), "flop_per_launch_executed": flop, "flop_per_launch_algorithmic": flop_alg,
                          "algorithmic_tflops": round(flop_alg / (wg_ms * 1e-3) / 1e12, 2)},
             "cpu_baseline": None}), flush=True)

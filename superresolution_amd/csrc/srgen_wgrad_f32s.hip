@@ -55,7 +55,8 @@ __device__ __forceinline__ h8 cat(h4 a, h4 b) { return __builtin_shufflevector(a
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_split_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                      int total_rows, int H, int W, int rows_per_slice,
                                                                      const float* __restrict__ dy_amax,
-                                                                     float* __restrict__ slab, float* __restrict__ bias_slab)
+                                                                     float* __restrict__ slab, float* __restrict__ bias_slab,
+                                                                     int abl)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -107,13 +108,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_split_kernel(const float
     // (lane: channel quad l % 8 of the ci tile, halo pixels l / 8 + 8 it of 66) ----
     f32x4 stage[9];
     const bool is_dy = w < 3;
+    const bool do_bias = ct == 0 && ky == 1;          // the workgroup type that sees every row of the slice
     const int sq = is_dy ? tid % 24 : lane & 7, sp0 = is_dy ? tid / 24 : lane >> 3;
     auto load_unit = [&](int u) {
-        const int row = r0 + u / nseg, seg = u % nseg;
+        const int row = (abl & 1) ? r0 + 1 : r0 + u / nseg, seg = u % nseg;      // abl: timing experiments only
         if (is_dy) {
-            const float* src = dy + ((size_t)row * W + seg * 64 + sp0) * 96 + 4 * sq;
+            const float* src = dy + ((size_t)row * W + seg * 64) * 96;      // wave-uniform; the thread's part is 32 bits
+            const int toff = sp0 * 96 + 4 * sq;
 #pragma unroll
-            for (int it = 0; it < 8; ++it) stage[it] = *(const f32x4*)(src + (size_t)it * 8 * 96);
+            for (int it = 0; it < 8; ++it) stage[it] = *(const f32x4*)(src + it * 8 * 96 + toff);
         } else {
             const float* src = x + (size_t)(row + ky - 1) * W * 96 + 32 * ct + 4 * sq;
 #pragma unroll
@@ -139,12 +142,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_split_kernel(const float
     auto convert = [&](int u, int it, int b) {        // it < 8 for dY, < 9 for X
         char* base = lds + b * BUF_BYTES;
         if (is_dy) {
-            bsum += stage[it];
+            if (do_bias) bsum += stage[it];
             split_store(stage[it] * in_mul, base + (sp0 + 8 * it) * DY_PITCH + sq * 8, DYH, DYL);
         } else {
             const int r = sp0 + 8 * it;
             const int xx = (u % nseg) * 64 + r - 1;
-            const bool ok = (unsigned)xx < (unsigned)W;
+            const bool ok = (it != 0 && it != 8) || (unsigned)xx < (unsigned)W;      // only halo pixels 0 and 65 can be outside
             if (r < X_ROWS) split_store(ok ? stage[it] : f32x4{0.f, 0.f, 0.f, 0.f}, base + r * X_PITCH + sq * 8, XH, XL);
         }
     };
@@ -193,11 +196,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_split_kernel(const float
             const char* pa = base + offA + c * 64;
             const h8 ah = cat(tr_read(pa + DYH), tr_read(pa + DYH + 4 * DY_PITCH));
             const h8 al = cat(tr_read(pa + DYL), tr_read(pa + DYL + 4 * DY_PITCH));
-            if (more) {                               // a third of the next unit's split under these MFMAs
+            if (more && !(abl & 2)) {                 // a third of the next unit's split under these MFMAs
 #pragma unroll
                 for (int k = 0; k < 3; ++k)
                     if (3 * c + k < 8 || !is_dy) convert(un, 3 * c + k, b ^ 1);
             }
+            if (!(abl & 4))
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 acc[kx][c] = MFMA_H(al, bh[kx], acc[kx][c]);
@@ -239,7 +243,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_split_kernel(const float
         const int kx = t9 / 3, c = t9 % 3;
         *(f32x4*)(o + ((size_t)(ky * 3 + kx) * 96 + 32 * c + m) * 96 + 32 * ct + 4 * n4) = *(const f32x4*)(red + (t9 * 32 + m) * 32 + 4 * n4);
     }
-    if (ct == 0 && ky == 1 && tid < 96) {             // every row of the slice went through this workgroup
+    if (do_bias && tid < 96) {             // every row of the slice went through this workgroup
         const int quad = tid >> 2, e = tid & 3;
         float s = 0.f;
 #pragma unroll
@@ -285,7 +289,7 @@ hipError_t launch_conv3x3_wgrad_split_partial(const float* x, const float* dy, i
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
     hipLaunchKernelGGL(conv3x3_wgrad_split_kernel, dim3((unsigned)(slices * 9)), dim3(256), LDS_BYTES, s, x, dy, total_rows, h, h,
-                       rps, dy_amax, slab, bias_slab);
+                       rps, dy_amax, slab, bias_slab, getenv("SRGEN_WGRAD_ABL") ? atoi(getenv("SRGEN_WGRAD_ABL")) : 0);
     *slices_out = slices;
     return hipGetLastError();
 }
