@@ -379,14 +379,16 @@ std::vector<int> identity_perm(int n)
     return v;
 }
 
+// fp32: only the image of the handle's kernel path (split / wino / direct, fixed at srgen_create) is packed -- the
+// Winograd image alone is an fp64 G g Gt over 96 x 96 filters per conv (every commit packed all of them)
 ConvDev emit_conv3x3(Blob& blob, const Folded& f, int cb, const std::vector<int>& perm,
-                     const std::vector<float>* slope_src, bool slope_scalar)
+                     const std::vector<float>* slope_src, bool slope_scalar, bool split, bool wino)
 {
     ConvDev d;
     d.cout_blocks = cb;
-    d.w_f32 = blob.put_f32(pack3x3_f32(f, cb, perm));
-    d.w_wino = blob.put_f32(pack3x3_wino_f32(f, cb, perm));
-    d.w_split = blob.put_u16(pack3x3_split_f16(f, cb, perm));
+    if (split) d.w_split = blob.put_u16(pack3x3_split_f16(f, cb, perm));
+    else if (wino) d.w_wino = blob.put_f32(pack3x3_wino_f32(f, cb, perm));
+    else d.w_f32 = blob.put_f32(pack3x3_f32(f, cb, perm));
     d.w_bf16 = blob.put_u16(pack3x3_bf16(f, cb, perm));
     std::vector<float> bias((size_t)cb * 96), slope((size_t)cb * 96, 1.f);
     for (int i = 0; i < cb * 96; ++i) {
@@ -531,9 +533,9 @@ int srgen_commit_weights(srgen_handle* h, void* stream)
     for (int i = 0; i < h->cfg.num_blocks; ++i) {                        // Generator.py:30-42
         const std::string p = "blocks." + std::to_string(seq_index(i)) + ".block";
         Folded f1 = fold(h, p + ".0", p + ".1", 1.0, 96, 96, 3);
-        h->conv1.push_back(emit_conv3x3(blob, f1, 1, id96, &h->tensors.at(p + ".2.weight"), false));
+        h->conv1.push_back(emit_conv3x3(blob, f1, 1, id96, &h->tensors.at(p + ".2.weight"), false, h->f32_split, h->f32_wino));
         Folded f2 = fold(h, p + ".3", p + ".4", 0.1, 96, 96, 3);
-        h->conv2.push_back(emit_conv3x3(blob, f2, 1, id96, nullptr, false));
+        h->conv2.push_back(emit_conv3x3(blob, f2, 1, id96, nullptr, false, h->f32_split, h->f32_wino));
         if (i == 7 || i == 15) {                                          // Generator.py:15-27
             const std::string q = "blocks." + std::to_string(seq_index(i) + 1) + ".fc";
             CaDev& c = h->ca[i == 7 ? 0 : 1];
@@ -545,7 +547,7 @@ int srgen_commit_weights(srgen_handle* h, void* stream)
     }
     {   // mid: conv + BN                                                  Generator.py:61-64
         Folded f = fold(h, "mid.0", "mid.1", 1.0, 96, 96, 3);
-        h->mid = emit_conv3x3(blob, f, 1, id96, nullptr, false);
+        h->mid = emit_conv3x3(blob, f, 1, id96, nullptr, false, h->f32_split, h->f32_wino);
     }
     {   // upsample conv 96 -> 384; PixelShuffle(2): out[c][2y+i][2x+j] = conv[4c+2i+j][y][x]
         // (Generator.py:7-8), so packed block b = 2i+j holds original channels 4c+b.
@@ -553,18 +555,18 @@ int srgen_commit_weights(srgen_handle* h, void* stream)
         std::vector<int> perm(384);
         for (int b = 0; b < 4; ++b)
             for (int c = 0; c < 96; ++c) perm[b * 96 + c] = 4 * c + b;
-        h->up = emit_conv3x3(blob, f, 4, perm, &h->tensors.at("upsample.act.weight"), true);
+        h->up = emit_conv3x3(blob, f, 4, perm, &h->tensors.at("upsample.act.weight"), true, h->f32_split, h->f32_wino);
     }
     {   // output[0] + scalar PReLU                                        Generator.py:69-70
         Folded f = fold(h, "output.0", "", 1.0, 96, 96, 3);
-        h->out0 = emit_conv3x3(blob, f, 1, id96, &h->tensors.at("output.1.weight"), true);
+        h->out0 = emit_conv3x3(blob, f, 1, id96, &h->tensors.at("output.1.weight"), true, h->f32_split, h->f32_wino);
     }
     {   // head 9x9 96 -> 3                                                Generator.py:71
         Folded f = fold(h, "output.2", "", 1.0, 3, 96, 9);
         h->head = ConvDev();
-        h->head.w_f32 = blob.put_f32(pack_head_f32(f));
+        if (h->f32_split) h->head.w_split = blob.put_u16(pack_head_split_f16(f));
+        else h->head.w_f32 = blob.put_f32(pack_head_f32(f));
         h->head.w_bf16 = blob.put_u16(pack_head_bf16(f));
-        h->head.w_split = blob.put_u16(pack_head_split_f16(f));
         h->head.bias = blob.put_f32(f.b);
     }
 
