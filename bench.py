@@ -151,21 +151,21 @@ def training_leg(args, dev, rank, n_ranks, use_dist):
     lr = torch.rand((n, 3, 64, 64), generator=gen).to(dev)
     hr = torch.rand((n, 3, 125, 125), generator=gen).to(dev)
     if args.workload == "cfg3":
-        step = T.PretrainStep(g, lr=1e-4)
+        step = T.PretrainStep(g, lr=1e-4, precision=args.train_precision)
         run = lambda: step.step(lr, hr)
-        name = f"BASELINE.json configs[3]: pre-train step (forward, loss, backward, AdamW), {n} images per GPU, fp32"
+        name = f"BASELINE.json configs[3]: pre-train step (forward, loss, backward, AdamW), {n} images per GPU, fp32 tensors"
         metric = "pre-train step images/s"
     else:
         torch.manual_seed(3)
         d = Discriminator().to(dev).train()
-        gan = GanStep(g, d)
+        gan = GanStep(g, d, precision=args.train_precision)
         it = [0]
 
         def run():
             it[0] += 1
             return gan.step(lr, hr, update_d=(it[0] - 1) % 3 == 0)["g_loss"]      # config.py:21 discriminator_update_freq = 3
         name = (f"BASELINE.json configs[4]: GAN iteration (discriminator half-step every 3rd iteration + generator "
-                f"half-step), {n} images per GPU, fp32")
+                f"half-step), {n} images per GPU, fp32 tensors")
         metric = "GAN iteration images/s"
 
     def barrier():
@@ -193,17 +193,19 @@ def training_leg(args, dev, rank, n_ranks, use_dist):
     if T.wgrad_path() == "split":
         xa.amax_slots = T.absmax(xa)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(21)]
-    for _ in range(3):
-        T.conv3x3_wgrad(xa, xa, ws)
-    ev[0].record()
-    for i in range(20):
-        T.conv3x3_wgrad(xa, xa, ws)
-        ev[i + 1].record()
-    ev[-1].synchronize()
+    with T.conv_precision(args.train_precision):
+        for _ in range(3):
+            T.conv3x3_wgrad(xa, xa, ws)
+        ev[0].record()
+        for i in range(20):
+            T.conv3x3_wgrad(xa, xa, ws)
+            ev[i + 1].record()
+        ev[-1].synchronize()
     wg_ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(20))[10]
     flop_alg = 2.0 * n * 4096 * 96 * 864
     wpath = T.wgrad_path()
-    ratio, peak, kname = ((SPLIT_EXECUTED, PEAK["f16"], "wgs::conv3x3_wgrad_split_kernel + conv3x3_wgrad_reduce_kernel") if wpath == "split"
+    f16 = args.train_precision == "f16"
+    ratio, peak, kname = ((1.0 if f16 else SPLIT_EXECUTED, PEAK["f16"], f"wgs::conv3x3_wgrad_split_kernel<{1 if f16 else 3}> + conv3x3_wgrad_reduce_kernel") if wpath == "split"
                           else (WINO_EXECUTED, PEAK["f32"], "conv3x3_wgrad_wino_lds_kernel + sum + final") if wpath == "wino"
                           else (1.0, PEAK["f32"], "conv3x3_wgrad_kernel + reduce"))
     flop = flop_alg * ratio
@@ -211,8 +213,14 @@ def training_leg(args, dev, rank, n_ranks, use_dist):
         print(json.dumps({
             "metric": metric, "value": round(n * n_ranks * args.steps / dt, 1), "unit": "images/s", "n_gpus": n_ranks,
             "steps": args.steps, "warmup": max(args.warmup, 3), "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16 products, f32 accumulation and tensors" if f16 else "f32", "data": "synthetic",
             "config": {"workload": name, "batch_per_gpu": n, "global_batch": n * n_ranks, "parallelism": f"dp{n_ranks}",
+                       "conv_products": ("f16: the generator's 3x3 convs (forward, data and weight gradient) multiply operands "
+                                         "rounded to f16 after power-of-two range scaling, one MFMA per product -- the reference "
+                                         "runs this step under bf16 autocast (train.py:91); tests/test_gpu_training.py shows the "
+                                         "gradients closer to the reference's fp32 step than its own autocast step is") if f16
+                                        else "fp32 accuracy (three f16 MFMAs per product)",
                        "precision": f"fp32 tensors and accumulation; 3x3 conv products: {T.conv_path()} (forward, data "
                                     f"gradient), {wpath} (weight gradient) -- split = two-term f16 splits of both "
                                     "operands, three f16 MFMAs per product, operands range-scaled by powers of two",
@@ -236,6 +244,9 @@ def main():
     ap.add_argument("--workload", choices=["cfg1", "cfg2", "cfg3", "cfg4"], default="cfg1",
                     help="which leg is the headline `value` (cfg3 / cfg4: the training steps, their own line)")
     ap.add_argument("--train-batch", type=int, default=64, help="images per GPU per training step (cfg3 / cfg4)")
+    ap.add_argument("--train-precision", choices=["fp32", "f16"], default="fp32",
+                    help="cfg3 / cfg4: products of the generator's 3x3 convs -- fp32 (three f16 MFMAs per product) or f16 "
+                         "(operands rounded to f16, fp32 accumulation: what the reference's bf16 autocast does to its convs)")
     ap.add_argument("--batch", type=int, default=BATCH, help="images per GPU per step (cfg1)")
     ap.add_argument("--cfg2-reps", type=int, default=5)
     ap.add_argument("--median-steps", type=int, default=50, help="HIP-event-timed steps of the median leg (>= 50)")

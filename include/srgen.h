@@ -215,6 +215,13 @@ SRGEN_API int srgen_split_pack(const float* w_oihw, int cout_total, int mode, in
 SRGEN_API int srgen_absmax(const float* x, size_t numel, float* out, void* stream);
 SRGEN_API int srgen_conv3x3_nhwc_split(const float* x, const void* wpack, const float* bias, const float* res, float* out,
                                        int n, int hw, int cout_blocks, int shuffle, const float* in_amax, void* stream);
+/* Mixed-precision variant of the operator above: the counterpart of F.conv2d inside the reference's
+ * `with torch.autocast(device_type='cuda', dtype=torch.bfloat16)` blocks (train.py:91-92,148-149,166-167), where the conv
+ * runs on operands rounded to a 16-bit type with fp32 accumulation.  Same arguments, same weight image (its high parts
+ * alone are read), same power-of-two range scaling; operands are rounded to f16 (11 significant bits against bf16's 8),
+ * ONE f16 MFMA per product instead of three; tensors stay fp32. */
+SRGEN_API int srgen_conv3x3_nhwc_f16(const float* x, const void* wpack, const float* bias, const float* res, float* out,
+                                     int n, int hw, int cout_blocks, int shuffle, const float* in_amax, void* stream);
 
 /* Replaces: the weight / bias gradient of F.conv2d(x, w, b, padding=1): dw (96, 96, 3, 3) OIHW =
  * sum over pixels dy[n,y,x,co] * x[n,y+ky-1,x+kx-1,ci]; dbias [96] = sum dy (NULL to skip).  Fixed summation order. */
@@ -226,6 +233,10 @@ SRGEN_API int srgen_conv3x3_wgrad(const float* x, const float* dy, int n, int hw
  * NULL for a dy of order 1: gradients are scaled by a power of two into f16's range before they are split. */
 SRGEN_API int srgen_conv3x3_wgrad_split(const float* x, const float* dy, int n, int hw, const float* dy_amax, float* dw,
                                         float* dbias, void* scratch, size_t scratch_bytes, void* stream);
+/* Mixed-precision variant (see srgen_conv3x3_nhwc_f16): x and the scaled dy rounded to f16, one MFMA per product, fp32
+ * accumulation and fp32 dw / dbias; the weight gradient of a conv that ran under the reference's autocast. */
+SRGEN_API int srgen_conv3x3_wgrad_f16(const float* x, const float* dy, int n, int hw, const float* dy_amax, float* dw,
+                                      float* dbias, void* scratch, size_t scratch_bytes, void* stream);
 
 /* Replaces: nn.BatchNorm2d(96) in train mode (+ PReLU(96), + the residual add) forward and backward
  * (Generator.py:35-36,38,42).  c: conv output (npix, 96), kept for the backward.

@@ -60,15 +60,18 @@ __device__ __forceinline__ int opaque(int v)
     return v;
 }
 
-// acc += hi_w hi_x + lo_w hi_x + hi_w lo_x, small terms first
+// acc += hi_w hi_x + lo_w hi_x + hi_w lo_x, small terms first (TERMS = 1: hi_w hi_x alone -- f16 products)
+template <int TERMS>
 __device__ __forceinline__ void mma_tap(f32x16 (&acc)[2][3], const Frags& f)
 {
 #pragma unroll
     for (int nt = 0; nt < 3; ++nt)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
-            acc[mt][nt] = MFMA_H(f.wl[nt], f.xh[mt], acc[mt][nt]);
-            acc[mt][nt] = MFMA_H(f.wh[nt], f.xl[mt], acc[mt][nt]);
+            if (TERMS == 3) {
+                acc[mt][nt] = MFMA_H(f.wl[nt], f.xh[mt], acc[mt][nt]);
+                acc[mt][nt] = MFMA_H(f.wh[nt], f.xl[mt], acc[mt][nt]);
+            }
             acc[mt][nt] = MFMA_H(f.wh[nt], f.xh[mt], acc[mt][nt]);
         }
 }
@@ -76,7 +79,7 @@ __device__ __forceinline__ void mma_tap(f32x16 (&acc)[2][3], const Frags& f)
 struct Item { int n, ty, tx, cb; };
 
 // ABL: timing ablations for tools/bench_f32s.hip only (wrong results); the library instantiates ABL = 0
-template <int HW, bool SHUFFLE, bool POOL, bool RES, int ABL = 0>
+template <int HW, bool SHUFFLE, bool POOL, bool RES, int ABL = 0, int TERMS = 3>
 __global__ __launch_bounds__(256, 2) void conv3x3_f32s_kernel(Conv3x3Args a, int nitems)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32s_kernel(Conv3x3Args a, int
         for (int e = 0; e < 4; ++e) {
             const float v = ok ? stage[it][e] * in_mul : 0.f;
             chi[it][e] = (_Float16)v;
-            clo[it][e] = (_Float16)(v - (float)chi[it][e]);
+            if (TERMS == 3) clo[it][e] = (_Float16)(v - (float)chi[it][e]);
         }
     };
     auto store_a = [&]() {
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32s_kernel(Conv3x3Args a, int
             if (it < A_REGS - 1 || i < A_ITEMS) {
                 char* rec = ldsA + (i >> 2) * PSB + (i & 3) * 8;
                 *(h4*)rec = chi[it];
-                *(h4*)(rec + 32) = clo[it];
+                if (TERMS == 3) *(h4*)(rec + 32) = clo[it];
             }
         }
     };
@@ -193,7 +196,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32s_kernel(Conv3x3Args a, int
         const char* src = (const char*)a.wpack + ((size_t)cb * 18 + g) * WG_BYTES;
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
-            const int piece = w + 4 * k;
+            // TERMS = 1: only the nine pieces of high parts (even piece indices)
+            const int piece = TERMS == 3 ? w + 4 * k : 2 * (w + 4 * k);
             if (piece < 18) {
                 const unsigned la = lds_base + W_OFF + slot * WG_BYTES + piece * 1024;
                 asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
@@ -267,17 +271,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32s_kernel(Conv3x3Args a, int
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 f.xh[mt] = *(const h8*)(ab + mt * 32 * PSB);
-                f.xl[mt] = *(const h8*)(ab + mt * 32 * PSB + 32);
+                if (TERMS == 3) f.xl[mt] = *(const h8*)(ab + mt * 32 * PSB + 32);
             }
             const char* wb = Wl + slot * WG_BYTES + kx * (3 * 2 * 64 * 16);
 #pragma unroll
             for (int nt = 0; nt < 3; ++nt) {
                 f.wh[nt] = *(const h8*)(wb + (nt * 2) * 1024);
-                f.wl[nt] = *(const h8*)(wb + (nt * 2 + 1) * 1024);
+                if (TERMS == 3) f.wl[nt] = *(const h8*)(wb + (nt * 2 + 1) * 1024);
             }
         };
 
         Frags f0, f1;
+        constexpr int NMF = 6 * TERMS, NDS = TERMS == 3 ? 10 : 5;     // MFMAs / fragment reads of one tap
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
 #pragma unroll
@@ -300,6 +305,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32s_kernel(Conv3x3Args a, int
                     }
                 }
                 const bool cvt = ky == 2 && !(ABL & 1);
+                // a chunk's last group carries the split arithmetic and the LDS writes of the next chunk's pixels: it
+                // runs at raised priority, so of the two workgroups sharing a CU the one in plain MFMA groups yields
+                // issue slots to it (measured 3 % on the PReLU instantiation, 2 % with the residual; tools/bench_f32s)
+                if (ky == 2 && !(ABL & 4096)) __builtin_amdgcn_s_setprio(2);
                 if (!(ABL & 8) || g == 0) load_frags(f0, slot, ky, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 if (!(ABL & 8) || g == 0) load_frags(f1, slot, ky, 1);
@@ -307,13 +316,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32s_kernel(Conv3x3Args a, int
                     convert_a(0);
                     convert_a(1);
                 }
-                if (!(ABL & 4)) mma_tap(acc, f0);
+                if (!(ABL & 4)) mma_tap<TERMS>(acc, f0);
                 if (cvt) {
-                    __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, NDS, 0);
 #pragma unroll
-                    for (int i = 0; i < 18; ++i) {
+                    for (int i = 0; i < NMF; ++i) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, TERMS == 3 ? 3 : 4, 0);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -323,13 +332,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32s_kernel(Conv3x3Args a, int
                     convert_a(3);
                     convert_a(4);
                 }
-                if (!(ABL & 4)) mma_tap(acc, f1);
+                if (!(ABL & 4)) mma_tap<TERMS>(acc, f1);
                 if (cvt) {
-                    __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, NDS, 0);
 #pragma unroll
-                    for (int i = 0; i < 18; ++i) {
+                    for (int i = 0; i < NMF; ++i) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, TERMS == 3 ? 4 : 6, 0);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -338,12 +347,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32s_kernel(Conv3x3Args a, int
                     convert_a(6);
                 }
                 if (RES && g == 17) load_res(cur, 0);
-                if (!(ABL & 4)) mma_tap(acc, f0);
+                if (!(ABL & 4)) mma_tap<TERMS>(acc, f0);
                 if (cvt) {
 #pragma unroll
-                    for (int i = 0; i < 18; ++i) {
+                    for (int i = 0; i < NMF; ++i) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, TERMS == 3 ? 3 : 4, 0);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -357,6 +366,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32s_kernel(Conv3x3Args a, int
                 if (ky == 0 && !(ABL & 1024)) __builtin_amdgcn_s_waitcnt(0x0077);      // vmcnt(7) lgkmcnt(0)
                 else wait_all();
                 if (!(ABL & 64)) barrier();
+                if (ky == 2 && !(ABL & 4096)) __builtin_amdgcn_s_setprio(0);
             }
         }
 
@@ -447,6 +457,12 @@ hipError_t launch_one(const Conv3x3Args& a, hipStream_t s)
 {
     const int nitems = a.N * (HW / TH) * (HW / TW) * (SHUFFLE ? 4 : 1);     // multiple of 16
     const int grid = nitems < MAX_WGS ? nitems & ~7 : MAX_WGS;
+    if (a.terms == 1) {
+        if (POOL) return hipErrorInvalidValue;        // the f16-product variant serves the training operators only
+        hipLaunchKernelGGL((conv3x3_f32s_kernel<HW, SHUFFLE, false, RES, 0, 1>), dim3((unsigned)grid), dim3(256), LDS_BYTES,
+                           s, a, nitems);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL((conv3x3_f32s_kernel<HW, SHUFFLE, POOL, RES>), dim3((unsigned)grid), dim3(256), LDS_BYTES,
                        s, a, nitems);
     return hipGetLastError();
@@ -457,7 +473,7 @@ hipError_t launch_one(const Conv3x3Args& a, hipStream_t s)
 hipError_t launch_conv3x3_f32_split(const Conv3x3Args& a, hipStream_t s)
 {
     using namespace c3s;
-    if (a.H != a.W || a.N <= 0) return hipErrorInvalidValue;
+    if (a.H != a.W || a.N <= 0 || (a.terms != 1 && a.terms != 3)) return hipErrorInvalidValue;
     const bool res = a.res != nullptr, pool = a.pool_partial != nullptr;
     if (a.H == kLR && !a.shuffle && a.cout_blocks == 1) {
         if (!pool && !res) return launch_one<kLR, false, false, false>(a, s);

@@ -52,6 +52,8 @@ struct Conv3x3Args {
     int in_amax_per_image = 0;        // 0: in_amax is ONE bound for the whole tensor (kAmaxSlots partial maxima: training
                                       // gradients); 1: in_amax is [N], one bound per image, and every image is scaled
                                       // by its own (eval forward: an image's result does not depend on its batch)
+    int terms = 3;                    // split kernel only: 3 = hi*hi + hi*lo + lo*hi (fp32 products), 1 = hi*hi alone (f16
+                                      // products, fp32 accumulation: the mixed-precision training convs)
     const float* in_amax = nullptr;   // split kernel only: kAmaxSlots device floats whose maximum is >= max |in| (any
                                       // bound within a few binades): the input is scaled by a power of two into f16's
                                       // range before it is split.  nullptr: no scaling (activations of order 1)
@@ -239,11 +241,12 @@ hipError_t launch_conv3x3_wgrad(const float* x, const float* dy, int n, int h, f
                                 hipStream_t s);
 // the same on the split arithmetic (srgen_wgrad_f32s.hip; h a multiple of 64); dy_amax: kAmaxSlots partial maxima of |dy|
 // or nullptr (dy of order 1); scratch of conv3x3_wgrad_scratch_bytes
+// terms: 3 (split products) or 1 (f16 products), as Conv3x3Args::terms
 hipError_t launch_conv3x3_wgrad_split(const float* x, const float* dy, int n, int h, const float* dy_amax, float* dw,
-                                      float* dbias, void* scratch, hipStream_t s);
+                                      float* dbias, void* scratch, hipStream_t s, int terms = 3);
 size_t conv3x3_wgrad_split_scratch_bytes(int n, int h);
 hipError_t launch_conv3x3_wgrad_split_partial(const float* x, const float* dy, int n, int h, const float* dy_amax,
-                                              float* slab, float* bias_slab, int* slices_out, hipStream_t s);
+                                              float* slab, float* bias_slab, int* slices_out, hipStream_t s, int terms = 3);
 size_t bn_bwd_scratch_bytes();
 // c: saved conv output; dt: gradient of the BatchNorm(+PReLU) output (scaled by dscale); stats: {mean, biased var}
 hipError_t launch_bn_train_bwd(const float* c, const float* dt, const float* stats, const float* gamma, const float* beta,

@@ -86,7 +86,7 @@ int srgen_split_pack(const float* w_oihw, int cout_total, int mode, int block, v
 }
 
 static int conv3x3_nhwc_any(const float* x, const void* wpack, const float* bias, const float* res, float* out, int n, int hw,
-                            int cout_blocks, int shuffle, void* stream, bool split, const float* in_amax);
+                            int cout_blocks, int shuffle, void* stream, bool split, const float* in_amax, int terms = 3);
 
 int srgen_absmax(const float* x, size_t numel, float* out, void* stream)
 {
@@ -108,8 +108,14 @@ int srgen_conv3x3_nhwc_split(const float* x, const void* wpack, const float* bia
     return conv3x3_nhwc_any(x, wpack, bias, res, out, n, hw, cout_blocks, shuffle, stream, true, in_amax);
 }
 
+int srgen_conv3x3_nhwc_f16(const float* x, const void* wpack, const float* bias, const float* res, float* out, int n, int hw,
+                           int cout_blocks, int shuffle, const float* in_amax, void* stream)
+{
+    return conv3x3_nhwc_any(x, wpack, bias, res, out, n, hw, cout_blocks, shuffle, stream, true, in_amax, 1);
+}
+
 static int conv3x3_nhwc_any(const float* x, const void* wpack, const float* bias, const float* res, float* out, int n, int hw,
-                            int cout_blocks, int shuffle, void* stream, bool split, const float* in_amax)
+                            int cout_blocks, int shuffle, void* stream, bool split, const float* in_amax, int terms)
 {
     if (!x || !wpack || !out) return fail(SRGEN_E_INVALID, "NULL argument");
     if (n <= 0) return fail(SRGEN_E_INVALID, "batch %d", n);
@@ -129,6 +135,7 @@ static int conv3x3_nhwc_any(const float* x, const void* wpack, const float* bias
     a.res = res; a.pool_partial = nullptr;
     if (in_amax && !aligned16(in_amax)) return fail(SRGEN_E_INVALID, "in_amax must be 16-byte aligned");
     a.in_amax = in_amax;
+    a.terms = terms;
     a.N = n; a.H = hw; a.W = hw; a.cout_blocks = cout_blocks; a.shuffle = shuffle;
     HIP_TRY(split ? launch_conv3x3_f32_split(a, (hipStream_t)stream) : launch_conv3x3_f32_wino(a, (hipStream_t)stream));
     return SRGEN_OK;
@@ -151,15 +158,30 @@ int srgen_conv3x3_wgrad(const float* x, const float* dy, int n, int hw, float* d
     return SRGEN_OK;
 }
 
+static int wgrad_split_any(const float* x, const float* dy, int n, int hw, const float* dy_amax, float* dw, float* dbias,
+                           void* scratch, size_t scratch_bytes, void* stream, int terms);
+
 int srgen_conv3x3_wgrad_split(const float* x, const float* dy, int n, int hw, const float* dy_amax, float* dw, float* dbias,
                               void* scratch, size_t scratch_bytes, void* stream)
+{
+    return wgrad_split_any(x, dy, n, hw, dy_amax, dw, dbias, scratch, scratch_bytes, stream, 3);
+}
+
+int srgen_conv3x3_wgrad_f16(const float* x, const float* dy, int n, int hw, const float* dy_amax, float* dw, float* dbias,
+                            void* scratch, size_t scratch_bytes, void* stream)
+{
+    return wgrad_split_any(x, dy, n, hw, dy_amax, dw, dbias, scratch, scratch_bytes, stream, 1);
+}
+
+static int wgrad_split_any(const float* x, const float* dy, int n, int hw, const float* dy_amax, float* dw, float* dbias,
+                           void* scratch, size_t scratch_bytes, void* stream, int terms)
 {
     if (!x || !dy || !dw || !scratch) return fail(SRGEN_E_INVALID, "NULL argument");
     if (n <= 0 || hw <= 0 || (hw & 63)) return fail(SRGEN_E_INVALID, "bad shape (n %d, hw %d: a multiple of 64)", n, hw);
     if (scratch_bytes < conv3x3_wgrad_scratch_bytes(n, hw)) return fail(SRGEN_E_WORKSPACE, "wgrad scratch too small");
     if (!aligned16(x) || !aligned16(dy) || (dy_amax && !aligned16(dy_amax)))
         return fail(SRGEN_E_INVALID, "operands must be 16-byte aligned");
-    HIP_TRY(launch_conv3x3_wgrad_split(x, dy, n, hw, dy_amax, dw, dbias, scratch, (hipStream_t)stream));
+    HIP_TRY(launch_conv3x3_wgrad_split(x, dy, n, hw, dy_amax, dw, dbias, scratch, (hipStream_t)stream, terms));
     return SRGEN_OK;
 }
 

@@ -52,6 +52,9 @@ __device__ __forceinline__ h4 tr_read(const char* p)
 }
 __device__ __forceinline__ h8 cat(h4 a, h4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
 
+// TERMS = 3: split products (hi hi + hi lo + lo hi); TERMS = 1: products of the operands rounded to f16 (the mixed-precision
+// training step: the counterpart of the reference's autocast convs, train.py:91), a third of the MFMAs and no low parts
+template <int TERMS>
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_split_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                      int total_rows, int H, int W, int rows_per_slice,
                                                                      const float* __restrict__ dy_amax,
@@ -132,12 +135,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_split_kernel(const float
         h4 hi4, lo4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float hi = __uint_as_float(__float_as_uint(v[e]) & 0xFFFFE000u);
-            hi4[e] = (_Float16)hi;
-            lo4[e] = (_Float16)(v[e] - hi);
+            if (TERMS == 3) {
+                const float hi = __uint_as_float(__float_as_uint(v[e]) & 0xFFFFE000u);
+                hi4[e] = (_Float16)hi;
+                lo4[e] = (_Float16)(v[e] - hi);
+            } else {
+                hi4[e] = (_Float16)v[e];              // rounded to nearest
+            }
         }
         *(h4*)(rec + hi_off) = hi4;
-        *(h4*)(rec + lo_off) = lo4;
+        if (TERMS == 3) *(h4*)(rec + lo_off) = lo4;
     };
     auto convert = [&](int u, int it, int b) {        // it < 8 for dY, < 9 for X
         char* base = lds + b * BUF_BYTES;
@@ -189,13 +196,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_split_kernel(const float
         for (int kx = 0; kx < 3; ++kx) {
             const char* pb = base + offB + kx * X_PITCH;
             bh[kx] = cat(tr_read(pb + XH), tr_read(pb + XH + 4 * X_PITCH));
-            bl[kx] = cat(tr_read(pb + XL), tr_read(pb + XL + 4 * X_PITCH));
+            if (TERMS == 3) bl[kx] = cat(tr_read(pb + XL), tr_read(pb + XL + 4 * X_PITCH));
         }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const char* pa = base + offA + c * 64;
             const h8 ah = cat(tr_read(pa + DYH), tr_read(pa + DYH + 4 * DY_PITCH));
-            const h8 al = cat(tr_read(pa + DYL), tr_read(pa + DYL + 4 * DY_PITCH));
+            h8 al;
+            if (TERMS == 3) al = cat(tr_read(pa + DYL), tr_read(pa + DYL + 4 * DY_PITCH));
             if (more && !(abl & 2)) {                 // a third of the next unit's split under these MFMAs
 #pragma unroll
                 for (int k = 0; k < 3; ++k)
@@ -204,8 +212,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_split_kernel(const float
             if (!(abl & 4))
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
-                acc[kx][c] = MFMA_H(al, bh[kx], acc[kx][c]);
-                acc[kx][c] = MFMA_H(ah, bl[kx], acc[kx][c]);
+                if (TERMS == 3) {
+                    acc[kx][c] = MFMA_H(al, bh[kx], acc[kx][c]);
+                    acc[kx][c] = MFMA_H(ah, bl[kx], acc[kx][c]);
+                }
                 acc[kx][c] = MFMA_H(ah, bh[kx], acc[kx][c]);
             }
         }
@@ -272,10 +282,10 @@ size_t conv3x3_wgrad_split_scratch_bytes(int n, int h)
 }
 
 hipError_t launch_conv3x3_wgrad_split_partial(const float* x, const float* dy, int n, int h, const float* dy_amax,
-                                              float* slab, float* bias_slab, int* slices_out, hipStream_t s)
+                                              float* slab, float* bias_slab, int* slices_out, hipStream_t s, int terms)
 {
     using namespace wgs;
-    if (n <= 0 || h <= 0 || (h & 63)) return hipErrorInvalidValue;
+    if (n <= 0 || h <= 0 || (h & 63) || (terms != 1 && terms != 3)) return hipErrorInvalidValue;
     const int total_rows = n * h;
     const int slices = conv3x3_wgrad_split_slices(total_rows);
     const int rps = (total_rows + slices - 1) / slices;
@@ -284,12 +294,19 @@ hipError_t launch_conv3x3_wgrad_split_partial(const float* x, const float* dy, i
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        e = hipFuncSetAttribute((const void*)conv3x3_wgrad_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        e = hipFuncSetAttribute((const void*)conv3x3_wgrad_split_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)conv3x3_wgrad_split_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return e;
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL(conv3x3_wgrad_split_kernel, dim3((unsigned)(slices * 9)), dim3(256), LDS_BYTES, s, x, dy, total_rows, h, h,
-                       rps, dy_amax, slab, bias_slab, getenv("SRGEN_WGRAD_ABL") ? atoi(getenv("SRGEN_WGRAD_ABL")) : 0);
+    const int abl = getenv("SRGEN_WGRAD_ABL") ? atoi(getenv("SRGEN_WGRAD_ABL")) : 0;
+    if (terms == 1)
+        hipLaunchKernelGGL(conv3x3_wgrad_split_kernel<1>, dim3((unsigned)(slices * 9)), dim3(256), LDS_BYTES, s, x, dy, total_rows,
+                           h, h, rps, dy_amax, slab, bias_slab, abl);
+    else
+        hipLaunchKernelGGL(conv3x3_wgrad_split_kernel<3>, dim3((unsigned)(slices * 9)), dim3(256), LDS_BYTES, s, x, dy, total_rows,
+                           h, h, rps, dy_amax, slab, bias_slab, abl);
     *slices_out = slices;
     return hipGetLastError();
 }

@@ -22,7 +22,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from . import _lib
-from .training import FlatAdamW, PretrainStep, Workspace, pixel_loss_grad
+from .training import FlatAdamW, PretrainStep, Workspace, conv_precision, pixel_loss_grad, resolve_precision
 
 SLOPE = 0.2                                  # nn.LeakyReLU(0.2), Discriminator.py:10,24,36
 
@@ -207,8 +207,12 @@ class GanStep:
 
     def __init__(self, generator, discriminator, lr_g: float = 1e-4, lr_d: float = 1e-6, weight_adversarial: float = 0.005,
                  weight_pixel: float = 1.0, weight_ssim: float = 0.3, grad_clip_norm: float = 10.0, real_label: float = 0.9,
-                 fake_label: float = 0.1, group=None):
-        self.gen = PretrainStep(generator, lr=lr_g, ssim_weight=weight_ssim, l1_weight=weight_pixel, group=group)
+                 fake_label: float = 0.1, group=None, precision: str = "auto"):
+        # precision: the generator's 3x3 conv products, as PretrainStep ("auto": f16 products when called inside
+        # torch.autocast with a 16-bit dtype, the way train.py:148-149,166-167 call the generator); the discriminator's
+        # convs stay on the exact-fp32 MFMA
+        self.gen = PretrainStep(generator, lr=lr_g, ssim_weight=weight_ssim, l1_weight=weight_pixel, group=group,
+                                precision=precision)
         self.opt_g = self.gen.optimizer
         self.ws = self.gen.ws
         self.d = discriminator
@@ -239,6 +243,10 @@ class GanStep:
     def d_step(self, lr_img: torch.Tensor, hr_img: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """Updates the discriminator; returns (d_loss, real_logits) -- the logits the generator step of the same iteration
         uses (computed BEFORE the update, as in the reference)."""
+        with conv_precision(resolve_precision(self.gen.precision)):
+            return self._d_step(lr_img, hr_img)
+
+    def _d_step(self, lr_img: torch.Tensor, hr_img: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         if not self.gen.g.training:
             raise RuntimeError("GanStep runs the generator in train mode (train.py:132): call generator.train()")
         # train-mode forward without a graph (train.py:147-149): batch statistics, running stats move.  Through the step's
@@ -265,6 +273,10 @@ class GanStep:
 
     # train.py:165-176
     def g_step(self, lr_img: torch.Tensor, hr_img: torch.Tensor, real_logits: torch.Tensor) -> Dict[str, torch.Tensor]:
+        with conv_precision(resolve_precision(self.gen.precision)):
+            return self._g_step(lr_img, hr_img, real_logits)
+
+    def _g_step(self, lr_img: torch.Tensor, hr_img: torch.Tensor, real_logits: torch.Tensor) -> Dict[str, torch.Tensor]:
         from .functional import pixel_losses
         if not self.gen.g.training:
             raise RuntimeError("GanStep runs the generator in train mode (train.py:132): call generator.train()")

@@ -11,6 +11,7 @@ conv to bf16; the fp32 operators here are the stricter computation of the same s
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 import os
 from typing import Dict, Optional, Tuple
@@ -96,6 +97,42 @@ def wgrad_path() -> str:
     return v
 
 
+# ---- precision of the 3x3 convs (forward, data gradient, weight gradient) ---------------------------------------------
+# "fp32": every product to fp32 accuracy (split path: three f16 MFMAs per product; or the exact-fp32 MFMA kernels).
+# "f16":  the operands rounded to f16 after the power-of-two range scaling, ONE MFMA per product, fp32 accumulation,
+#         fp32 tensors -- the counterpart of the reference's `with torch.autocast('cuda', dtype=torch.bfloat16)` around the
+#         generator call (train.py:91-92,148-149,166-167), where every conv runs on 16-bit operands.  f16 keeps 11
+#         significant bits against bf16's 8, so this mode sits between the reference's autocast step and its fp32 step
+#         (tests/test_gpu_training.py: closer to the fp32 gradients than the reference's own autocast gradients are).
+_CONV_PRECISION = ["fp32"]
+
+
+@contextlib.contextmanager
+def conv_precision(precision: str):
+    """Within the block ``conv3x3`` / ``conv3x3_wgrad`` run at ``precision`` ("fp32" | "f16"; split path only)."""
+    if precision not in ("fp32", "f16"):
+        raise RuntimeError(f"conv precision '{precision}': expected fp32 or f16")
+    if precision == "f16" and conv_path() != "split":
+        raise RuntimeError("f16 conv products exist on the split path only (SRGEN_F32_CONV3X3 unset or 'split')")
+    old = _CONV_PRECISION[0]
+    _CONV_PRECISION[0] = precision
+    try:
+        yield
+    finally:
+        _CONV_PRECISION[0] = old
+
+
+def resolve_precision(precision: str) -> str:
+    """``"auto"`` -> "f16" when the caller is inside ``torch.autocast`` for ROCm devices with a 16-bit dtype (the way the
+    reference runs its training forward, train.py:91) and the split path is active, else "fp32"."""
+    if precision != "auto":
+        return precision
+    if torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") in (torch.bfloat16, torch.float16) \
+            and conv_path() == "split":
+        return "f16"
+    return "fp32"
+
+
 def conv_pack(w: torch.Tensor, mode: int = 0, block: int = 0) -> torch.Tensor:
     """The weight image ``conv3x3`` wants for the selected kernel (``conv_path``)."""
     return split_pack(w, mode, block) if conv_path() == "split" else wino_pack(w, mode, block)
@@ -135,9 +172,9 @@ def conv3x3(x: torch.Tensor, wpack: torch.Tensor, bias: Optional[torch.Tensor] =
                 amax = getattr(x, "amax_slots", None)
                 if amax is None:
                     amax = absmax(x)
-            _lib.check(_lib.lib().srgen_conv3x3_nhwc_split(x.data_ptr(), wpack.data_ptr(), pb, pr, out.data_ptr(), n, hw,
-                                                           cout_blocks, 1 if shuffle else 0,
-                                                           amax.data_ptr() if amax is not None else None, _stream(x)))
+            op = _lib.lib().srgen_conv3x3_nhwc_f16 if _CONV_PRECISION[0] == "f16" else _lib.lib().srgen_conv3x3_nhwc_split
+            _lib.check(op(x.data_ptr(), wpack.data_ptr(), pb, pr, out.data_ptr(), n, hw, cout_blocks, 1 if shuffle else 0,
+                          amax.data_ptr() if amax is not None else None, _stream(x)))
         else:
             _lib.check(_lib.lib().srgen_conv3x3_nhwc(x.data_ptr(), wpack.data_ptr(), pb, pr, out.data_ptr(), n, hw,
                                                      cout_blocks, 1 if shuffle else 0, _stream(x)))
@@ -172,8 +209,9 @@ def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, ws: Workspace, dw: Optional
             amax = getattr(dy, "amax_slots", None)
             if amax is None:
                 amax = absmax(dy)
-            _lib.check(L.srgen_conv3x3_wgrad_split(x.data_ptr(), dy.data_ptr(), n, hw, amax.data_ptr(), dw.data_ptr(),
-                                                   db.data_ptr(), scratch.data_ptr(), scratch.numel(), _stream(x)))
+            op = L.srgen_conv3x3_wgrad_f16 if _CONV_PRECISION[0] == "f16" else L.srgen_conv3x3_wgrad_split
+            _lib.check(op(x.data_ptr(), dy.data_ptr(), n, hw, amax.data_ptr(), dw.data_ptr(), db.data_ptr(),
+                          scratch.data_ptr(), scratch.numel(), _stream(x)))
         else:
             _lib.check(L.srgen_conv3x3_wgrad(x.data_ptr(), dy.data_ptr(), n, hw, dw.data_ptr(), db.data_ptr(),
                                              scratch.data_ptr(), scratch.numel(), _stream(x)))
@@ -480,11 +518,18 @@ class PretrainStep:
 
     composed from the HIP operators above; gradients land in ``p.grad`` (views of ``optimizer.flat_grad``, so the
     reference's ``grad_norm`` (train.py:23-28) and a data-parallel all-reduce of ONE 12.86 MB buffer work unchanged),
-    BatchNorm running statistics are updated as ``nn.BatchNorm2d`` does.  fp32 (see the module docstring).  With
+    BatchNorm running statistics are updated as ``nn.BatchNorm2d`` does.  Tensors are fp32; ``precision`` picks the 3x3
+    conv products: "fp32", "f16" (16-bit operands, fp32 accumulation: what the reference's bf16 autocast does to its
+    convs) or "auto" (default: "f16" when ``step`` is called inside ``torch.autocast`` with a 16-bit dtype, as train.py:91
+    calls the generator, else "fp32"; see ``conv_precision``).  With
     ``world_size > 1`` (one process per GPU, ``torch.distributed`` initialised) ``step`` averages ``flat_grad`` over the
     ranks with one all-reduce before the update, as DistributedDataParallel would."""
 
-    def __init__(self, generator, lr: float = 1e-4, ssim_weight: float = 0.1, l1_weight: float = 1.0, group=None):
+    def __init__(self, generator, lr: float = 1e-4, ssim_weight: float = 0.1, l1_weight: float = 1.0, group=None,
+                 precision: str = "auto"):
+        if precision not in ("auto", "fp32", "f16"):
+            raise RuntimeError(f"precision '{precision}': expected auto, fp32 or f16")
+        self.precision = precision
         p0 = next(generator.parameters())
         if not p0.is_cuda:
             raise RuntimeError("PretrainStep needs the generator on a ROCm device; there is no CPU fallback")
@@ -598,11 +643,12 @@ class PretrainStep:
         if not self.g.training:
             raise RuntimeError("PretrainStep runs the generator in train mode (train.py:81): call generator.train()")
         hr = hr_img.detach().to(torch.float32).contiguous()
-        sr, S = self.forward(lr_img)
-        vals = pixel_losses(sr, hr)                                         # [psnr, ssim, l1, weighted_l1]
-        loss = self.l1_weight * vals[3] + self.ssim_weight * (1.0 - vals[1])
-        dsr = pixel_loss_grad(sr, hr, self.ws, self.l1_weight, self.ssim_weight)
-        self.backward(dsr, S)
+        with conv_precision(resolve_precision(self.precision)):
+            sr, S = self.forward(lr_img)
+            vals = pixel_losses(sr, hr)                                     # [psnr, ssim, l1, weighted_l1]
+            loss = self.l1_weight * vals[3] + self.ssim_weight * (1.0 - vals[1])
+            dsr = pixel_loss_grad(sr, hr, self.ws, self.l1_weight, self.ssim_weight)
+            self.backward(dsr, S)
         self._update_running_stats(S, sr.shape[0])
         self.last_metrics = vals
         return loss

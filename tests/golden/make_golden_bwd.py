@@ -21,6 +21,12 @@ seed 0, lr batch = 3 dense + 1 sparse images (seed 2, as generator_train.npz), h
 loss = weighted_l1 + 0.1 * (1 - ssim), loss.backward():
   loss, sr_sample; keys = parameter names in named_parameters() order; grad_sums (n_params, 2) = {sum, sum of squares} of
   every gradient (fp64); grad_absmax; grad_sample_<key> for a handful of tensors (stride-7 samples).
+
+`python tests/golden/make_golden_bwd.py step_autocast` writes train_step_autocast.npz: the SAME step the way the reference
+really runs it (train.py:91-94): forward and loss inside torch.autocast(dtype=bfloat16) (device type 'cpu' here: no GPU in
+the build container), backward outside.  Stored: loss; grad_sample_<key> for the keys of train_step.npz; grad_rel_err
+(n_params) = |g_autocast - g_fp32| / |g_fp32| (2-norms) of every parameter gradient and flat_cosine of the whole gradient
+against the fp32 step: the reference's OWN mixed-precision deviation, the bar for this library's f16-product mode.
 """
 import importlib.util
 import os
@@ -140,5 +146,47 @@ def main_step():
     print("wrote train_step.npz: loss", loss.item(), "params", len(names))
 
 
+SAMPLE_KEYS = ("input.0.weight", "input.1.weight", "blocks.0.block.0.weight", "blocks.8.fc.0.weight", "blocks.8.fc.2.bias",
+               "blocks.16.block.3.weight", "blocks.17.fc.2.weight", "mid.0.weight", "mid.1.weight", "upsample.conv.weight",
+               "upsample.conv.bias", "upsample.act.weight", "output.0.weight", "output.1.weight", "output.2.weight",
+               "output.2.bias")
+
+
+def main_step_autocast():
+    torch.set_num_threads(8)
+    G = load_ref("ref_generator", "Generator.py")
+    U = load_ref("ref_utils", "utils.py")
+    lr = torch.from_numpy(np.concatenate([W.synthetic_lr_batch(3, 2, "dense"), W.synthetic_lr_batch(1, 2, "sparse")], 0))
+    hr = torch.from_numpy(W.synthetic_hr_batch(4, seed=1))
+    grads, losses = {}, {}
+    for tag in ("fp32", "autocast"):
+        g = G.Generator()
+        g.load_state_dict(W.synthetic_state_dict(0), strict=True)
+        g.train()
+        with torch.autocast(device_type="cpu", dtype=torch.bfloat16, enabled=tag == "autocast"):
+            sr = g(lr)
+            loss = weighted_l1(sr, hr) + 0.1 * (1 - U.ssim(sr, hr))
+        loss.backward()
+        grads[tag] = {k: p.grad.detach().double() for k, p in g.named_parameters()}
+        losses[tag] = float(loss.item())
+    names = list(grads["fp32"].keys())
+    rel = np.array([((grads["autocast"][k] - grads["fp32"][k]).norm() / grads["fp32"][k].norm()).item() for k in names])
+    fa = torch.cat([grads["autocast"][k].flatten() for k in names])
+    f3 = torch.cat([grads["fp32"][k].flatten() for k in names])
+    out = {"loss": np.array(losses["autocast"]), "loss_fp32": np.array(losses["fp32"]), "keys": np.array(names),
+           "grad_rel_err": rel, "flat_cosine": np.array((fa @ f3 / (fa.norm() * f3.norm())).item()),
+           "flat_rel_err": np.array(((fa - f3).norm() / f3.norm()).item())}
+    for k in SAMPLE_KEYS:
+        out["grad_sample_" + k] = grads["autocast"][k].float().flatten()[::7].numpy()
+    np.savez_compressed(os.path.join(OUT, "train_step_autocast.npz"), **out)
+    print("wrote train_step_autocast.npz: loss", losses, "flat cosine", out["flat_cosine"], "flat rel err", out["flat_rel_err"],
+          "median / max per-parameter rel err", np.median(rel), rel.max())
+
+
 if __name__ == "__main__":
-    main_step() if sys.argv[1:] == ["step"] else main()
+    if sys.argv[1:] == ["step"]:
+        main_step()
+    elif sys.argv[1:] == ["step_autocast"]:
+        main_step_autocast()
+    else:
+        main()

@@ -314,3 +314,89 @@ def test_pretrain_step_updates_parameters_and_running_stats():
     assert torch.isfinite(y).all()
     assert max_rel(y.cpu().numpy(), y2.cpu().numpy()) <= 1e-6
     assert max_rel(y.cpu().numpy(), y0.cpu().numpy()) >= 1e-3
+
+
+# ---- mixed precision: f16 conv products (the counterpart of the reference's bf16 autocast, train.py:91) -----------------
+F16_TOL = 2e-3            # operands rounded to 11 significant bits, fp32 accumulation: ~1e-4 of max on these sums; a conv
+                          # on bf16 operands (what the reference's autocast runs) is at ~1e-3
+
+
+@pytest.mark.parametrize("shape,scale", [((3, 96, 64, 64), 1.0), ((2, 96, 128, 128), 2.0 ** -22), ((5, 96, 64, 64), 2.0 ** 9)])
+def test_conv3x3_f16_products_vs_torch_fp64(shape, scale):
+    """srgen_conv3x3_nhwc_f16 / srgen_conv3x3_wgrad_f16 (forward, data gradient, weight gradient) against torch in fp64:
+    inside F16_TOL, and NOT inside the fp32 bar (the switch really changes the arithmetic); gradients far outside f16's
+    range are scaled like on the split path; the fp32 mode is untouched after the block."""
+    from superresolution_amd import training as T
+    torch.manual_seed(7)
+    w = (torch.rand(96, 96, 3, 3) - 0.5) * 0.1
+    b = (torch.rand(96) - 0.5) * 0.1
+    x = _hash_tensor(61, "f16.x", shape)
+    gr = _hash_tensor(62, "f16.g", shape) * scale
+    xr, wr, br = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    yr = F.conv2d(xr, wr, br, padding=1)
+    (yr * gr.double()).sum().backward()
+    ws = T.Workspace(torch.device("cuda"))
+    wc, xc, gc = w.cuda(), _nhwc(x).cuda(), _nhwc(gr).cuda()
+    with T.conv_precision("f16"):
+        y = T.conv3x3(xc, T.split_pack(wc), b.cuda())
+        dx = T.conv3x3(gc, T.split_pack(wc, mode=1), scale_input=True)
+        dw, db = T.conv3x3_wgrad(xc, gc, ws)
+    errs = {"y": max_rel(_nchw(y).cpu().double().numpy(), yr.detach().numpy()),
+            "dx": max_rel(_nchw(dx).cpu().double().numpy(), xr.grad.numpy()),
+            "dw": max_rel(dw.cpu().double().numpy(), wr.grad.numpy()),
+            "db": max_rel(db.cpu().double().numpy(), br.grad.numpy())}
+    print("f16 products", shape, scale, errs)
+    assert all(e <= F16_TOL for e in errs.values()), errs
+    assert errs["y"] > 1e-5 and errs["dx"] > 1e-5 and errs["dw"] > 1e-6, errs      # one-term arithmetic, not the split one
+    assert errs["db"] <= 2e-5                                     # the bias gradient is summed from the fp32 values
+    y32 = T.conv3x3(xc, T.split_pack(wc), b.cuda())               # back on the default: fp32 products
+    assert max_rel(_nchw(y32).cpu().double().numpy(), yr.detach().numpy()) <= 2e-6
+
+
+def _sample_rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm(a - b) / np.linalg.norm(b))
+
+
+def test_pretrain_step_f16_products_vs_reference_fp32_and_autocast_golden():
+    """The pre-train step with f16 conv products (precision="f16", and "auto" inside torch.autocast as train.py:91 calls
+    it) against ONE step of the real reference run both ways (make_golden_bwd.py step / step_autocast): every sampled
+    gradient is closer to the reference's fp32 gradient than the reference's own bf16-autocast gradient is (every one of the
+    sixteen sampled tensors; by 2x at the median), the loss likewise."""
+    from superresolution_amd import Generator, training as T, weights as W
+    g32 = np.load(os.path.join(GOLDEN, "train_step.npz"))
+    gac = np.load(os.path.join(GOLDEN, "train_step_autocast.npz"))
+    lr, hr = _step_batch()
+    results = {}
+    for mode in ("f16", "auto"):
+        g = Generator()
+        g.load_state_dict(W.synthetic_state_dict(0))
+        g = g.cuda().train()
+        step = T.PretrainStep(g, lr=1e-4, precision=mode)
+        if mode == "auto":
+            with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+                assert T.resolve_precision("auto") == "f16"
+                loss = step.forward_backward(lr, hr)
+            assert T.resolve_precision("auto") == "fp32"
+        else:
+            loss = step.forward_backward(lr, hr)
+        P = dict(g.named_parameters())
+        results[mode] = (float(loss), {k: P[k[len("grad_sample_"):]].grad.detach().flatten()[::7].cpu().numpy()
+                                       for k in g32.files if k.startswith("grad_sample_")})
+    loss, grads = results["f16"]
+    ref_loss, ac_loss = float(g32["loss"]), float(gac["loss"])
+    print("loss: fp32 reference", ref_loss, "reference autocast", ac_loss, "this f16 step", loss)
+    assert abs(loss - ref_loss) <= 0.5 * abs(ac_loss - ref_loss)
+    ratios = []
+    for k, v in grads.items():
+        ours, theirs = _sample_rel(v, g32[k]), _sample_rel(gac[k], g32[k])
+        print(f"  {k}: this step {ours:.2e}, reference autocast {theirs:.2e}")
+        assert ours <= theirs and ours <= 2e-2, (k, ours, theirs)
+        ratios.append(ours / theirs)
+    print("  this step's deviation / the reference autocast's: median", float(np.median(ratios)), "max", max(ratios))
+    assert float(np.median(ratios)) <= 0.5
+    assert _sample_rel(grads["grad_sample_mid.0.weight"], g32["grad_sample_mid.0.weight"]) >= 1e-4    # (not the fp32 arithmetic)
+    # "auto" inside autocast ran the same arithmetic
+    assert results["auto"][0] == loss
+    for k, v in results["auto"][1].items():
+        assert np.array_equal(v, grads[k]), k

@@ -12,7 +12,7 @@
 
 using namespace srgen;
 
-template <int ABL, bool RES>
+template <int ABL, bool RES, int TERMS = 3>
 static int run(const char* name, Conv3x3Args a, int reps)
 {
     using namespace c3s;
@@ -22,11 +22,11 @@ static int run(const char* name, Conv3x3Args a, int reps)
     CK_(hipEventCreate(&e0));
     CK_(hipEventCreate(&e1));
     for (int i = 0; i < 10; ++i)
-        hipLaunchKernelGGL((conv3x3_f32s_kernel<64, false, false, RES, ABL>), dim3(grid), dim3(256), LDS_BYTES, 0, a, nitems);
+        hipLaunchKernelGGL((conv3x3_f32s_kernel<64, false, false, RES, ABL, TERMS>), dim3(grid), dim3(256), LDS_BYTES, 0, a, nitems);
     CK_(hipDeviceSynchronize());
     CK_(hipEventRecord(e0, 0));
     for (int i = 0; i < reps; ++i)
-        hipLaunchKernelGGL((conv3x3_f32s_kernel<64, false, false, RES, ABL>), dim3(grid), dim3(256), LDS_BYTES, 0, a, nitems);
+        hipLaunchKernelGGL((conv3x3_f32s_kernel<64, false, false, RES, ABL, TERMS>), dim3(grid), dim3(256), LDS_BYTES, 0, a, nitems);
     CK_(hipEventRecord(e1, 0));
     CK_(hipEventSynchronize(e1));
     CK_(hipGetLastError());
@@ -81,6 +81,11 @@ int main(int argc, char** argv)
         printf("-- round %d\n", round);
         if (run<256, false>("full", a, reps)) return 1;
         if (run<256, true>("full + residual", ar, reps)) return 1;
+        if (run<256, false, 1>("one term (f16 products)", a, reps)) return 1;
+        if (run<256, true, 1>("one term + residual", ar, reps)) return 1;
+        if (run<256 + 4096, false, 1>("one term, no raised priority", a, reps)) return 1;
+        if (run<256 + 4, false, 1>("one term, no MFMA", a, reps)) return 1;
+        if (run<256 + 4096, false>("no raised priority in a chunk's last group", a, reps)) return 1;
         if (run<256 + 1, false>("no pixel staging (load, split, LDS write)", a, reps)) return 1;
         if (run<256 + 4, false>("no MFMA", a, reps)) return 1;
         if (run<256 + 8, false>("no fragment LDS reads", a, reps)) return 1;
