@@ -244,6 +244,7 @@ hipError_t launch_conv3x3_wgrad(const float* x, const float* dy, int n, int h, f
 // terms: 3 (split products) or 1 (f16 products), as Conv3x3Args::terms
 hipError_t launch_conv3x3_wgrad_split(const float* x, const float* dy, int n, int h, const float* dy_amax, float* dw,
                                       float* dbias, void* scratch, hipStream_t s, int terms = 3);
+constexpr int kWgradSplitMaxSlices = 168;         // slab = [slices][9][96][96] floats, then [slices][96] bias partials
 size_t conv3x3_wgrad_split_scratch_bytes(int n, int h);
 hipError_t launch_conv3x3_wgrad_split_partial(const float* x, const float* dy, int n, int h, const float* dy_amax,
                                               float* slab, float* bias_slab, int* slices_out, hipStream_t s, int terms = 3);

@@ -627,8 +627,8 @@ hipError_t launch_conv3x3_wgrad_split(const float* x, const float* dy, int n, in
 {
     int slices = 0;
     float* slab = (float*)scratch;
-    // (the bias partials sit behind the largest slab the slice count can ask for: 112 slices)
-    float* bias_slab = slab + (size_t)112 * 9 * 9216;
+    // (the bias partials sit behind the largest slab the slice count can ask for)
+    float* bias_slab = slab + (size_t)kWgradSplitMaxSlices * 9 * 9216;
     hipError_t e = launch_conv3x3_wgrad_split_partial(x, dy, n, h, dy_amax, slab, bias_slab, &slices, s, terms);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3(9 * 9216 / 64), dim3(256), 0, s, slab, bias_slab, slices, dw, dbias);

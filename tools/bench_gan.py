@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--precision", choices=["fp32", "f16"], default="fp32", help="generator 3x3 conv products")
     args = ap.parse_args()
     import torch
     from superresolution_amd import Discriminator, Generator, weights as W
@@ -28,7 +29,7 @@ def main():
     g = g.to(dev).train()
     torch.manual_seed(3)
     d = Discriminator().to(dev).train()
-    step = GanStep(g, d)
+    step = GanStep(g, d, precision=args.precision)
     gen = torch.Generator(device="cpu").manual_seed(7)
     lr = torch.rand((args.batch, 3, 64, 64), generator=gen).to(dev)
     hr = torch.rand((args.batch, 3, 125, 125), generator=gen).to(dev)

@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--precision", choices=["fp32", "f16"], default="fp32", help="3x3 conv products (training.conv_precision)")
     ap.add_argument("--ops", action="store_true", help="time the trunk operators one by one instead of the step")
     args = ap.parse_args()
     import torch
@@ -60,7 +61,7 @@ def main():
     g = Generator()
     g.load_state_dict(W.synthetic_state_dict(0))
     g = g.to(dev).train()
-    step = T.PretrainStep(g, lr=1e-4)
+    step = T.PretrainStep(g, lr=1e-4, precision=args.precision)
     gen = torch.Generator(device="cpu").manual_seed(7)
     lr = torch.rand((args.batch, 3, 64, 64), generator=gen).to(dev)
     hr = torch.rand((args.batch, 3, 125, 125), generator=gen).to(dev)
@@ -79,13 +80,14 @@ def main():
     e = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
     step.optimizer.zero_grad()
     e[0].record()
-    sr, S = step.forward(lr)
-    e[1].record()
-    vals = pixel_losses(sr, hr)
-    dsr = T.pixel_loss_grad(sr, hr, step.ws, 1.0, 0.1)
-    e[2].record()
-    step.backward(dsr, S)
-    e[3].record()
+    with T.conv_precision(args.precision):
+        sr, S = step.forward(lr)
+        e[1].record()
+        vals = pixel_losses(sr, hr)
+        dsr = T.pixel_loss_grad(sr, hr, step.ws, 1.0, 0.1)
+        e[2].record()
+        step.backward(dsr, S)
+        e[3].record()
     step.optimizer.step()
     e[4].record()
     e[4].synchronize()
@@ -94,12 +96,12 @@ def main():
     # stem's data gradient: 2 x forward - 2 x 95.55 MMAC
     flop = args.batch * (3 * 2 * 14_407_045_632 - 2 * 95_551_488)
     print(json.dumps({"metric": "pre-train step images/s (configs[3], one GPU)", "value": round(args.batch / (med * 1e-3), 1),
-                      "unit": "images/s", "batch": args.batch, "dtype": "f32", "median_ms_per_step": round(med, 3),
+                      "unit": "images/s", "batch": args.batch, "dtype": "f32", "conv_products": args.precision, "median_ms_per_step": round(med, 3),
                       "min_ms_per_step": round(ms[0], 3), "steps": args.steps, "loss_last": float(loss),
                       "phases_ms": {"forward": round(ph[0], 3), "loss+grad": round(ph[1], 3), "backward": round(ph[2], 3),
                                     "adamw": round(ph[3], 3)},
                       "algorithmic_tflops": round(flop / (med * 1e-3) / 1e12, 1),
-                      "note": "fp32 tensors; forward and data-gradient convs on the split-f16 kernel (SRGEN_F32_CONV3X3), weight gradients in the Winograd domain on the fp32 MFMA; the reference runs this step under bf16 autocast"}))
+                      "note": "fp32 tensors; 3x3 convs (forward, data and weight gradient) on the split kernels: fp32 = three f16 MFMAs per product, f16 = one (operands rounded to f16; the reference runs this step under bf16 autocast)"}))
 
 
 if __name__ == "__main__":
