@@ -205,7 +205,7 @@ def training_leg(args, dev, rank, n_ranks, use_dist):
     flop_alg = 2.0 * n * 4096 * 96 * 864
     wpath = T.wgrad_path()
     f16 = args.train_precision == "f16"
-    ratio, peak, kname = ((1.0 if f16 else SPLIT_EXECUTED, PEAK["f16"], f"wgs::conv3x3_wgrad_split_kernel<{1 if f16 else 3}> + conv3x3_wgrad_reduce_kernel") if wpath == "split"
+    ratio, peak, kname = ((1.0 if f16 else SPLIT_EXECUTED, PEAK["f16"], f"wg1::conv3x3_wgrad_split_kernel<{1 if f16 else 3}> + conv3x3_wgrad_reduce_kernel") if wpath == "split"
                           else (WINO_EXECUTED, PEAK["f32"], "conv3x3_wgrad_wino_lds_kernel + sum + final") if wpath == "wino"
                           else (1.0, PEAK["f32"], "conv3x3_wgrad_kernel + reduce"))
     flop = flop_alg * ratio
