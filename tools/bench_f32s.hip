@@ -85,6 +85,12 @@ int main(int argc, char** argv)
         if (run<256, true, 1>("one term + residual", ar, reps)) return 1;
         if (run<256 + 4096, false, 1>("one term, no raised priority", a, reps)) return 1;
         if (run<256 + 4, false, 1>("one term, no MFMA", a, reps)) return 1;
+        if (run<256 + 16, false, 1>("one term, no global loads", a, reps)) return 1;
+        if (run<256 + 2048, false, 1>("one term, pixel loads from L2 (image 0)", a, reps)) return 1;
+        if (run<256 + 1, false, 1>("one term, no pixel staging", a, reps)) return 1;
+        if (run<256 + 8, false, 1>("one term, no fragment LDS reads", a, reps)) return 1;
+        if (run<256 + 64 + 2, false, 1>("one term, no barriers", a, reps)) return 1;
+        if (run<256 + 1024, false, 1>("one term, vmcnt(0) in a chunk's first group", a, reps)) return 1;
         if (run<256 + 4096, false>("no raised priority in a chunk's last group", a, reps)) return 1;
         if (run<256 + 1, false>("no pixel staging (load, split, LDS write)", a, reps)) return 1;
         if (run<256 + 4, false>("no MFMA", a, reps)) return 1;
