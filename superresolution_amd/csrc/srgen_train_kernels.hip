@@ -261,34 +261,58 @@ __global__ __launch_bounds__(192) void conv3x3_wgrad_kernel(const float* __restr
     }
 }
 
-// 64 outputs x 4 slice groups per block; group g adds slices g, g+4, ... (four loads in flight), LDS joins the groups
-__global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const float* __restrict__ slab,
-                                                                   const float* __restrict__ bias_slab, int slices,
-                                                                   float* __restrict__ dw, float* __restrict__ dbias)
+// dbias[c] = sum over slices of bias_slab[slice][c], by one block of 1024 threads: ten groups of 96 threads take every
+// tenth slice (a single thread walking all slices waited one memory round trip per slice: 20 us of a 23 us kernel),
+// `red` (>= 960 floats of LDS, free after a barrier) joins them in fixed order
+__device__ __forceinline__ void bias_slab_sum(const float* __restrict__ bias_slab, int slices, float* __restrict__ dbias,
+                                              float* red)
 {
-    __shared__ float part[4][64];
+    const int t = threadIdx.x, c = t % 96, q = t / 96;
+    __syncthreads();
+    if (t < 960) {
+        float s = 0.f;
+        for (int sl = q; sl < slices; sl += 10) s += bias_slab[(size_t)sl * 96 + c];
+        red[t] = s;
+    }
+    __syncthreads();
+    if (t < 96) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) s += red[k * 96 + t];
+        dbias[t] = s;
+    }
+}
+
+// 64 outputs x 16 slice groups per block; group g adds slices g, g+16, ... (up to four loads in flight per thread, all of a
+// thread's loads within one or two round trips), LDS joins the groups in fixed order.  (Four groups: 23 us at 80 slices)
+__global__ __launch_bounds__(1024) void conv3x3_wgrad_reduce_kernel(const float* __restrict__ slab,
+                                                                    const float* __restrict__ bias_slab, int slices,
+                                                                    float* __restrict__ dw, float* __restrict__ dbias)
+{
+    __shared__ float part[16][64];
     const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int idx = blockIdx.x * 64 + o;                     // over tap * 9216 + co * 96 + ci  (9 * 9216 = 1296 * 64)
     const int tap = idx / 9216, rem = idx % 9216;
     {
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         int sl = g;
-        for (; sl + 12 < slices; sl += 16) {
+        for (; sl + 48 < slices; sl += 64) {
             s0 += slab[((size_t)sl * 9 + tap) * 9216 + rem];
-            s1 += slab[((size_t)(sl + 4) * 9 + tap) * 9216 + rem];
-            s2 += slab[((size_t)(sl + 8) * 9 + tap) * 9216 + rem];
-            s3 += slab[((size_t)(sl + 12) * 9 + tap) * 9216 + rem];
+            s1 += slab[((size_t)(sl + 16) * 9 + tap) * 9216 + rem];
+            s2 += slab[((size_t)(sl + 32) * 9 + tap) * 9216 + rem];
+            s3 += slab[((size_t)(sl + 48) * 9 + tap) * 9216 + rem];
         }
-        for (; sl < slices; sl += 4) s0 += slab[((size_t)sl * 9 + tap) * 9216 + rem];
+        for (; sl < slices; sl += 16) s0 += slab[((size_t)sl * 9 + tap) * 9216 + rem];
         part[g][o] = (s0 + s1) + (s2 + s3);
     }
     __syncthreads();
-    if (g == 0) dw[(size_t)rem * 9 + tap] = (part[0][o] + part[1][o]) + (part[2][o] + part[3][o]);   // OIHW
-    if (dbias && blockIdx.x == 0 && threadIdx.x < 96) {
+    if (g == 0) {
         float s = 0.f;
-        for (int sl = 0; sl < slices; ++sl) s += bias_slab[(size_t)sl * 96 + threadIdx.x];
-        dbias[threadIdx.x] = s;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += part[k][o];
+        dw[(size_t)rem * 9 + tap] = s;                       // OIHW
     }
+    if (dbias && blockIdx.x == 0) bias_slab_sum(bias_slab, slices, dbias, &part[0][0]);
 }
 
 // ---- conv3x3 weight gradient in the Winograd domain (the default) ---------------------------------------------------
@@ -631,7 +655,7 @@ hipError_t launch_conv3x3_wgrad_split(const float* x, const float* dy, int n, in
     float* bias_slab = slab + (size_t)kWgradSplitMaxSlices * 9 * 9216;
     hipError_t e = launch_conv3x3_wgrad_split_partial(x, dy, n, h, dy_amax, slab, bias_slab, &slices, s, terms);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3(9 * 9216 / 64), dim3(256), 0, s, slab, bias_slab, slices, dw, dbias);
+    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3(9 * 9216 / 64), dim3(1024), 0, s, slab, bias_slab, slices, dw, dbias);
     return hipGetLastError();
 }
 
@@ -661,7 +685,7 @@ hipError_t launch_conv3x3_wgrad(const float* x, const float* dy, int n, int h, f
                        slices, slab, bias_slab);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3(9 * 9216 / 64), dim3(256), 0, s, slab, bias_slab, slices,
+    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3(9 * 9216 / 64), dim3(1024), 0, s, slab, bias_slab, slices,
                        dw, dbias);
     return hipGetLastError();
 }
@@ -1245,29 +1269,35 @@ __global__ __launch_bounds__(256) void conv9x9_c3_wgrad_kernel(const float* __re
     }
 }
 
-__global__ __launch_bounds__(256) void conv9x9_c3_wgrad_reduce_kernel(const float* __restrict__ slab,
-                                                                      const float* __restrict__ bias_slab, int slices,
-                                                                      float* __restrict__ r, float* __restrict__ dbias)
+// 64 outputs x 16 slice groups per block (as conv3x3_wgrad_reduce_kernel; one thread per output over 256 slices: 63 us)
+__global__ __launch_bounds__(1024) void conv9x9_c3_wgrad_reduce_kernel(const float* __restrict__ slab,
+                                                                       const float* __restrict__ bias_slab, int slices,
+                                                                       float* __restrict__ r, float* __restrict__ dbias)
 {
-    const int idx = blockIdx.x * 256 + threadIdx.x;              // over c * 256 + j
-    if (idx < 96 * 256) {
-        const int c = idx >> 8, j = idx & 255;
-        if (j < 243) {
-            float s0 = 0.f, s1 = 0.f;
-            int sl = 0;
-            for (; sl + 1 < slices; sl += 2) {
-                s0 += slab[(size_t)sl * 96 * 256 + idx];
-                s1 += slab[(size_t)(sl + 1) * 96 * 256 + idx];
-            }
-            if (sl < slices) s0 += slab[(size_t)sl * 96 * 256 + idx];
-            r[c * 243 + j] = s0 + s1;
+    __shared__ float part[16][64];
+    const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + o;                         // over c * 256 + j  (96 * 256 = 384 * 64)
+    {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int sl = g;
+        for (; sl + 48 < slices; sl += 64) {
+            s0 += slab[(size_t)sl * 96 * 256 + idx];
+            s1 += slab[(size_t)(sl + 16) * 96 * 256 + idx];
+            s2 += slab[(size_t)(sl + 32) * 96 * 256 + idx];
+            s3 += slab[(size_t)(sl + 48) * 96 * 256 + idx];
         }
+        for (; sl < slices; sl += 16) s0 += slab[(size_t)sl * 96 * 256 + idx];
+        part[g][o] = (s0 + s1) + (s2 + s3);
     }
-    if (dbias && idx < 96) {
+    __syncthreads();
+    const int c = idx >> 8, j = idx & 255;
+    if (g == 0 && j < 243) {
         float s = 0.f;
-        for (int sl = 0; sl < slices; ++sl) s += bias_slab[(size_t)sl * 96 + idx];
-        dbias[idx] = s;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += part[k][o];
+        r[c * 243 + j] = s;
     }
+    if (dbias && blockIdx.x == 0) bias_slab_sum(bias_slab, slices, dbias, &part[0][0]);
 }
 
 static int wgrad9_slices(int total_rows) { return total_rows < 1024 ? (total_rows + 3) / 4 : 256; }
@@ -1288,7 +1318,7 @@ hipError_t launch_conv9x9_c3_wgrad(const float* act, const float* img, int n, in
     float* bias_slab = slab + (size_t)slices * 96 * 256;
     hipLaunchKernelGGL(conv9x9_c3_wgrad_kernel, dim3((unsigned)slices), dim3(256), 0, s, act, img, total_rows, ah, aw, ih, iw, flip,
                        rps, slab, bias_slab);
-    hipLaunchKernelGGL(conv9x9_c3_wgrad_reduce_kernel, dim3((96 * 256 + 255) / 256), dim3(256), 0, s, slab, bias_slab, slices, r,
+    hipLaunchKernelGGL(conv9x9_c3_wgrad_reduce_kernel, dim3(96 * 256 / 64), dim3(1024), 0, s, slab, bias_slab, slices, r,
                        dbias);
     return hipGetLastError();
 }
