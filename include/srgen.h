@@ -212,6 +212,12 @@ SRGEN_API int srgen_conv3x3_nhwc(const float* x, const float* wpack, const float
  *                     stay below the f16 maximum 65,504. */
 #define SRGEN_AMAX_SLOTS 1024
 SRGEN_API int srgen_split_pack(const float* w_oihw, int cout_total, int mode, int block, void* out, void* stream);
+/* srgen_split_pack for `count` (<= 96) weights in two launches: what a training step does for the images of all its 3x3
+ * convs (forward and data-gradient images of the live weights, train.py:91-95), where one launch pair per image is launch
+ * latency only.  The arrays are HOST arrays of `count` entries: device pointers w_oihw[i] / out[i] and the arguments of
+ * srgen_split_pack for job i. */
+SRGEN_API int srgen_split_pack_many(int count, const float* const* w_oihw, const int* cout_total, const int* mode,
+                                    const int* block, void* const* out, void* stream);
 SRGEN_API int srgen_absmax(const float* x, size_t numel, float* out, void* stream);
 SRGEN_API int srgen_conv3x3_nhwc_split(const float* x, const void* wpack, const float* bias, const float* res, float* out,
                                        int n, int hw, int cout_blocks, int shuffle, const float* in_amax, void* stream);

@@ -85,6 +85,8 @@ def lib() -> ctypes.CDLL:
     L.srgen_wino_pack.argtypes = [vp, i, i, i, vp, vp]
     L.srgen_conv3x3_nhwc.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, vp]
     L.srgen_split_pack.argtypes = [vp, i, i, i, vp, vp]
+    L.srgen_split_pack_many.argtypes = [i, ctypes.POINTER(vp), ctypes.POINTER(i), ctypes.POINTER(i), ctypes.POINTER(i),
+                                        ctypes.POINTER(vp), vp]
     L.srgen_conv3x3_nhwc_split.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, vp, vp]
     L.srgen_conv3x3_nhwc_f16.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, vp, vp]
     L.srgen_absmax.argtypes = [vp, sz, vp, vp]
@@ -133,7 +135,7 @@ def lib() -> ctypes.CDLL:
                  "srgen_conv9x9_c3_wgrad_scratch_bytes", "srgen_conv9x9_c3_wgrad", "srgen_head_nhwc", "srgen_head_nhwc_split", "srgen_chan_attn_nhwc",
                  "srgen_chan_attn_bwd_scratch_bytes", "srgen_chan_attn_bwd"):
         getattr(L, name).restype = i
-    for name in ("srgen_conv3x3_nhwc_f16", "srgen_conv3x3_wgrad_f16", "srgen_wino_pack", "srgen_conv3x3_nhwc", "srgen_split_pack", "srgen_conv3x3_nhwc_split", "srgen_absmax", "srgen_conv3x3_wgrad_scratch_bytes", "srgen_conv3x3_wgrad", "srgen_conv3x3_wgrad_split",
+    for name in ("srgen_split_pack_many", "srgen_conv3x3_nhwc_f16", "srgen_conv3x3_wgrad_f16", "srgen_wino_pack", "srgen_conv3x3_nhwc", "srgen_split_pack", "srgen_conv3x3_nhwc_split", "srgen_absmax", "srgen_conv3x3_wgrad_scratch_bytes", "srgen_conv3x3_wgrad", "srgen_conv3x3_wgrad_split",
                  "srgen_bn_train_scratch_bytes", "srgen_bn_train_fwd", "srgen_bn_train_bwd", "srgen_pixel_loss_grad",
                  "srgen_adamw"):
         getattr(L, name).restype = i

@@ -231,6 +231,11 @@ hipError_t launch_bn_train(float* t, size_t npix, const float* gamma, const floa
 hipError_t launch_wino_pack(const float* w, float* out, int cout_total, int mode, int block, hipStream_t s);
 // the same for the split-f16 kernel: out = kSplitImageBytes per cout block + kSplitTailBytes
 hipError_t launch_split_pack(const float* w, void* out, int cout_total, int mode, int block, hipStream_t s);
+// many images in two launches; job i: arguments as launch_split_pack
+constexpr int kSplitPackMaxJobs = 96;
+struct SplitPackJob { const float* w; void* out; int cout_total, mode, block, pad; };
+struct SplitPackJobs { SplitPackJob j[kSplitPackMaxJobs]; int count; };
+hipError_t launch_split_pack_many(const SplitPackJobs& jobs, hipStream_t s);
 // out[kAmaxSlots] = per-workgroup maxima of |x| (their maximum is max |x|)
 hipError_t launch_absmax(const float* x, size_t n, float* out, hipStream_t s);
 // out[i] = max |x[i]| per image (per_image floats each, a multiple of 4), zero_out[i] = 0

@@ -85,6 +85,24 @@ int srgen_split_pack(const float* w_oihw, int cout_total, int mode, int block, v
     return SRGEN_OK;
 }
 
+int srgen_split_pack_many(int count, const float* const* w_oihw, const int* cout_total, const int* mode, const int* block,
+                          void* const* out, void* stream)
+{
+    if (count <= 0 || count > kSplitPackMaxJobs) return fail(SRGEN_E_INVALID, "count %d: 1 .. %d", count, kSplitPackMaxJobs);
+    if (!w_oihw || !cout_total || !mode || !block || !out) return fail(SRGEN_E_INVALID, "NULL argument");
+    SplitPackJobs jobs;
+    jobs.count = count;
+    for (int i = 0; i < count; ++i) {
+        if (!w_oihw[i] || !out[i] || !aligned16(out[i])) return fail(SRGEN_E_INVALID, "job %d: NULL or misaligned pointer", i);
+        if (cout_total[i] != 96 && cout_total[i] != 384) return fail(SRGEN_E_UNSUPPORTED, "job %d: cout %d", i, cout_total[i]);
+        if ((mode[i] != 0 && mode[i] != 1) || block[i] < 0 || block[i] >= cout_total[i] / 96)
+            return fail(SRGEN_E_INVALID, "job %d: bad mode / block", i);
+        jobs.j[i] = SplitPackJob{w_oihw[i], out[i], cout_total[i], mode[i], block[i], 0};
+    }
+    HIP_TRY(launch_split_pack_many(jobs, (hipStream_t)stream));
+    return SRGEN_OK;
+}
+
 static int conv3x3_nhwc_any(const float* x, const void* wpack, const float* bias, const float* res, float* out, int n, int hw,
                             int cout_blocks, int shuffle, void* stream, bool split, const float* in_amax, int terms = 3);
 

@@ -129,7 +129,7 @@ hipError_t launch_absmax(const float* x, size_t n, float* out, hipStream_t s)
 }
 
 // 32 partial maxima of |w| into the image's tail (its own small launch: 32 workgroups), then the pack
-__global__ __launch_bounds__(256) void weight_absmax_kernel(const float* __restrict__ w, int n, float* tail)
+__device__ __forceinline__ void weight_absmax_body(const float* __restrict__ w, int n, float* tail)
 {
     float m = 0.f;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += 32 * 256) m = fmaxf(m, fabsf(w[i]));   // (4-byte aligned views)
@@ -137,8 +137,13 @@ __global__ __launch_bounds__(256) void weight_absmax_kernel(const float* __restr
     if (threadIdx.x == 0) tail[blockIdx.x] = m;
 }
 
-__global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict__ w, _Float16* __restrict__ out, int cb,
-                                                         int shuffle, int mode, int block, const float* tail)
+__global__ __launch_bounds__(256) void weight_absmax_kernel(const float* __restrict__ w, int n, float* tail)
+{
+    weight_absmax_body(w, n, tail);
+}
+
+__device__ __forceinline__ void split_pack_body(const float* __restrict__ w, _Float16* __restrict__ out, int cb, int shuffle,
+                                                int mode, int block, const float* tail)
 {
     const float sc = pow2f(split_tail_exp(tail, threadIdx.x & 63));
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -162,6 +167,42 @@ __global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict
             out[unit * 8 + e] = hi;
             out[(unit + 64) * 8 + e] = lo;
         }
+}
+
+__global__ __launch_bounds__(256) void split_pack_kernel(const float* __restrict__ w, _Float16* __restrict__ out, int cb,
+                                                         int shuffle, int mode, int block, const float* tail)
+{
+    split_pack_body(w, out, cb, shuffle, mode, block, tail);
+}
+
+// ---- many images in two launches (a training step packs 73 images of unchanged layout: 146 launches of ~5 us) ----------
+__global__ __launch_bounds__(256) void weight_absmax_many_kernel(SplitPackJobs jobs)
+{
+    const SplitPackJob j = jobs.j[blockIdx.y];
+    const int cb = j.mode == 0 ? j.cout_total / 96 : 1;
+    weight_absmax_body(j.w, j.cout_total * 864, (float*)((char*)j.out + (size_t)cb * kSplitImageBytes));
+}
+
+__global__ __launch_bounds__(256) void split_pack_many_kernel(SplitPackJobs jobs)
+{
+    const SplitPackJob j = jobs.j[blockIdx.y];
+    const int cb = j.mode == 0 ? j.cout_total / 96 : 1;
+    if ((int)blockIdx.x * 256 >= cb * 96 * 96) return;
+    split_pack_body(j.w, (_Float16*)j.out, cb, j.cout_total == 384, j.mode, j.block,
+                    (const float*)((const char*)j.out + (size_t)cb * kSplitImageBytes));
+}
+
+hipError_t launch_split_pack_many(const SplitPackJobs& jobs, hipStream_t s)
+{
+    if (jobs.count <= 0 || jobs.count > kSplitPackMaxJobs) return hipErrorInvalidValue;
+    int max_cb = 1;
+    for (int i = 0; i < jobs.count; ++i)
+        if (jobs.j[i].mode == 0 && jobs.j[i].cout_total / 96 > max_cb) max_cb = jobs.j[i].cout_total / 96;
+    hipLaunchKernelGGL(weight_absmax_many_kernel, dim3(32, (unsigned)jobs.count), dim3(256), 0, s, jobs);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(split_pack_many_kernel, dim3((unsigned)(max_cb * 36), (unsigned)jobs.count), dim3(256), 0, s, jobs);
+    return hipGetLastError();
 }
 
 hipError_t launch_split_pack(const float* w, void* out, int cout_total, int mode, int block, hipStream_t s)

@@ -29,9 +29,8 @@
 // History (64-image gradient, with the reduction).  The first kernel of this file had workgroup = (slice, ci tile, ky),
 // the four waves splitting K: nine workgroup types per slice split the same dY row nine times and every X row three
 // times (1.2 GB through the vector memory path): 222 us (TERMS = 3) / 181 us (TERMS = 1, bound by staging alone).  This
-// one splits dY three times and X once: 156 us / 88 us.  TERMS = 1: two workgroups per CU (48 KB of LDS); TERMS = 3: one
-// (95 KB; a unit is 108 MFMAs per wave, about one trip to HBM).  80 slices x 3 = 240 workgroups keep the slab the
-// reduction reads small (168 slices: kernel 71 us, reduction 48).  Tried for TERMS = 1 and dropped: one workgroup per CU
+// one splits dY three times and X once: 137 us / 69 us.  TERMS = 1: two workgroups per CU (48 KB of LDS); TERMS = 3: one
+// (95 KB; a unit is 108 MFMAs per wave, about one trip to HBM).  Tried for TERMS = 1 and dropped: one workgroup per CU
 // with three staging register sets (loads two units ahead): 128 us -- the compiler's vmcnt(0) at the loop head and, once
 // the body was branch-free, its hoisting of every load in sight (86 spilled registers) undid the depth.
 #include "srgen_internal.h"
@@ -287,11 +286,12 @@ __global__ __launch_bounds__(256, TERMS == 3 ? 1 : 2) void conv3x3_wgrad_split_k
 
 }  // namespace wg1
 
-// slices: a multiple of 8 (XCD mapping); 3 workgroups per slice: 80 slices = 240 workgroups
-int conv3x3_wgrad_split_slices(int total_rows)
+// slices: a multiple of 8 (XCD mapping); 3 workgroups per slice.  TERMS = 3 (one workgroup per CU): 80 slices = 240
+// workgroups (120: 179 us, 168: 154 us against 137); TERMS = 1 (two per CU): 168 slices = 504 workgroups (68 us against 73)
+int conv3x3_wgrad_split_slices(int total_rows, int terms)
 {
     const char* e = getenv("SRGEN_WGRAD_SPLIT_SLICES");
-    int s = e ? atoi(e) & ~7 : 80;
+    int s = e ? atoi(e) & ~7 : (terms == 1 ? 168 : 80);
     if (s < 8 || s > kWgradSplitMaxSlices) s = kWgradSplitMaxSlices;
     while (s > 8 && total_rows < s) s -= 8;
     return s;
@@ -318,7 +318,7 @@ hipError_t launch_conv3x3_wgrad_split_partial(const float* x, const float* dy, i
         if (e != hipSuccess) return e;
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    const int slices = conv3x3_wgrad_split_slices(total_rows);
+    const int slices = conv3x3_wgrad_split_slices(total_rows, terms);
     const int rps = (total_rows + slices - 1) / slices;
     if (terms == 1)
         hipLaunchKernelGGL(conv3x3_wgrad_split_kernel<1>, dim3((unsigned)(slices * 3)), dim3(256), Lds<1>::BYTES, s, x, dy,

@@ -22,7 +22,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from . import _lib
-from .training import FlatAdamW, PretrainStep, Workspace, conv_precision, pixel_loss_grad, resolve_precision
+from .training import FlatAdamW, PretrainStep, Workspace, conv_precision, packed_weights, pixel_loss_grad, resolve_precision
 
 SLOPE = 0.2                                  # nn.LeakyReLU(0.2), Discriminator.py:10,24,36
 
@@ -243,7 +243,7 @@ class GanStep:
     def d_step(self, lr_img: torch.Tensor, hr_img: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """Updates the discriminator; returns (d_loss, real_logits) -- the logits the generator step of the same iteration
         uses (computed BEFORE the update, as in the reference)."""
-        with conv_precision(resolve_precision(self.gen.precision)):
+        with conv_precision(resolve_precision(self.gen.precision)), packed_weights(self.gen.pack_jobs(backward=False)):
             return self._d_step(lr_img, hr_img)
 
     def _d_step(self, lr_img: torch.Tensor, hr_img: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -273,7 +273,7 @@ class GanStep:
 
     # train.py:165-176
     def g_step(self, lr_img: torch.Tensor, hr_img: torch.Tensor, real_logits: torch.Tensor) -> Dict[str, torch.Tensor]:
-        with conv_precision(resolve_precision(self.gen.precision)):
+        with conv_precision(resolve_precision(self.gen.precision)), packed_weights(self.gen.pack_jobs()):
             return self._g_step(lr_img, hr_img, real_logits)
 
     def _g_step(self, lr_img: torch.Tensor, hr_img: torch.Tensor, real_logits: torch.Tensor) -> Dict[str, torch.Tensor]:

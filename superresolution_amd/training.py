@@ -133,8 +133,63 @@ def resolve_precision(precision: str) -> str:
     return "fp32"
 
 
+def split_pack_many(jobs) -> list:
+    """``split_pack`` for a list of ``(weight, mode, block)`` in two launches (``srgen_split_pack_many``): the images, in
+    order, as views of one fp16 buffer."""
+    ws = []
+    for w, mode, block in jobs:
+        if not w.is_cuda or w.dtype != torch.float32 or w.dim() != 4 or tuple(w.shape[1:]) != (96, 3, 3):
+            raise RuntimeError(f"expected a ROCm fp32 (cout, 96, 3, 3) weight, got {tuple(w.shape)} on {w.device}")
+        ws.append(w.detach().contiguous())
+    dev = ws[0].device
+    sizes = [(w.shape[0] // 96 if mode == 0 else 1) * SPLIT_HALFS + SPLIT_TAIL_HALFS for w, (_, mode, _) in zip(ws, jobs)]
+    buf = torch.empty(sum(sizes), dtype=torch.float16, device=dev)         # every image size is a multiple of 16 bytes
+    outs, off = [], 0
+    for n in sizes:
+        outs.append(buf[off:off + n])
+        off += n
+    done = 0
+    with torch.cuda.device(dev):
+        while done < len(jobs):                                            # the C entry point takes up to 96 jobs
+            k = min(96, len(jobs) - done)
+            sl = slice(done, done + k)
+            vp, ci = ctypes.c_void_p, ctypes.c_int
+            _lib.check(_lib.lib().srgen_split_pack_many(
+                k, (vp * k)(*[w.data_ptr() for w in ws[sl]]), (ci * k)(*[w.shape[0] for w in ws[sl]]),
+                (ci * k)(*[m for _, m, _ in jobs[sl]]), (ci * k)(*[b for _, _, b in jobs[sl]]),
+                (vp * k)(*[o.data_ptr() for o in outs[sl]]), _stream(ws[0])))
+            done += k
+    return outs
+
+
+# Weight images made ahead of a step: inside ``packed_weights(jobs)`` ``conv_pack`` serves the images of the listed (weight,
+# mode, block) from ONE batched pack (two launches instead of two per image: 146 launches of ~5 us in a pre-train step).
+# The weights must not change inside the block (they do not: the optimizer steps after the backward).
+_PACKED = {}
+
+
+@contextlib.contextmanager
+def packed_weights(jobs):
+    if conv_path() != "split" or not jobs:
+        yield
+        return
+    outs = split_pack_many(jobs)
+    old = dict(_PACKED)
+    for (w, mode, block), o in zip(jobs, outs):
+        _PACKED[(w.data_ptr(), mode, block)] = o
+    try:
+        yield
+    finally:
+        _PACKED.clear()
+        _PACKED.update(old)
+
+
 def conv_pack(w: torch.Tensor, mode: int = 0, block: int = 0) -> torch.Tensor:
-    """The weight image ``conv3x3`` wants for the selected kernel (``conv_path``)."""
+    """The weight image ``conv3x3`` wants for the selected kernel (``conv_path``); inside ``packed_weights`` the image
+    made there."""
+    hit = _PACKED.get((w.data_ptr(), mode, block))
+    if hit is not None:
+        return hit
     return split_pack(w, mode, block) if conv_path() == "split" else wino_pack(w, mode, block)
 
 
@@ -541,6 +596,15 @@ class PretrainStep:
         self.ssim_weight, self.l1_weight, self.group = ssim_weight, l1_weight, group
         self.last_metrics = None
 
+    def pack_jobs(self, backward: bool = True) -> list:
+        """(weight, mode, block) of every 3x3 weight image a step uses: forward images, and the data-gradient images."""
+        g = self.g
+        ws = [m.block[i].weight for m in g.blocks if hasattr(m, "block") for i in (0, 3)] + [g.mid[0].weight, g.output[0].weight]
+        jobs = [(w, 0, 0) for w in ws] + [(g.upsample.conv.weight, 0, 0)]
+        if backward:
+            jobs += [(w, 1, 0) for w in ws] + [(g.upsample.conv.weight, 1, b) for b in range(4)]
+        return jobs
+
     # -- forward ------------------------------------------------------------------------------------------------------
     def forward(self, lr_img: torch.Tensor):
         g, ws = self.g, self.ws
@@ -643,7 +707,7 @@ class PretrainStep:
         if not self.g.training:
             raise RuntimeError("PretrainStep runs the generator in train mode (train.py:81): call generator.train()")
         hr = hr_img.detach().to(torch.float32).contiguous()
-        with conv_precision(resolve_precision(self.precision)):
+        with conv_precision(resolve_precision(self.precision)), packed_weights(self.pack_jobs()):
             sr, S = self.forward(lr_img)
             vals = pixel_losses(sr, hr)                                     # [psnr, ssim, l1, weighted_l1]
             loss = self.l1_weight * vals[3] + self.ssim_weight * (1.0 - vals[1])
