@@ -1341,7 +1341,12 @@ __global__ __launch_bounds__(1024) void conv9x9_c3_wgrad_reduce_kernel(const flo
     if (dbias && blockIdx.x == 0) bias_slab_sum(bias_slab, slices, dbias, &part[0][0]);
 }
 
-static int wgrad9_slices(int total_rows) { return total_rows < 1024 ? (total_rows + 3) / 4 : 256; }
+// two workgroups per CU once there are rows enough (one: 1.0 ms for the head's gradient at 64 images)
+static int wgrad9_slices(int total_rows)
+{
+    static const int cap = getenv("SRGEN_WGRAD9_SLICES") ? atoi(getenv("SRGEN_WGRAD9_SLICES")) : 512;
+    return total_rows < 4 * cap ? (total_rows + 3) / 4 : cap;
+}
 
 size_t conv9x9_c3_wgrad_scratch_bytes(int n, int ah)
 {
