@@ -41,6 +41,29 @@ def test_argument_errors_without_gpu():
     h = ctypes.c_void_p()
     assert L.srgen_create(ctypes.byref(cfg), ctypes.byref(h)) == -6 and h.value is None
     assert b"base_ch=96" in L.srgen_last_error()
+    # training operators: argument checks come before any HIP call too
+    assert L.srgen_split_pack_many(0, None, None, None, None, None, None) == -1
+    assert b"count" in L.srgen_last_error()
+    assert L.srgen_split_pack_many(97, None, None, None, None, None, None) == -1
+    assert L.srgen_split_pack_many(1, None, None, None, None, None, None) == -1 and b"NULL" in L.srgen_last_error()
+    assert L.srgen_conv3x3_nhwc_f16(None, None, None, None, None, 1, 64, 1, 0, None, None) == -1
+    assert L.srgen_conv3x3_wgrad_f16(None, None, 1, 64, None, None, None, None, 0, None) == -1
+
+
+def test_conv_precision_switch_on_the_host():
+    """training.conv_precision / resolve_precision: names are checked, the state is restored on exit and on error; off
+    the GPU there is no autocast for ROCm devices, so "auto" is fp32."""
+    from superresolution_amd import training as T
+    assert T.resolve_precision("auto") == "fp32" and T.resolve_precision("f16") == "f16"
+    with T.conv_precision("f16"):
+        assert T._CONV_PRECISION[0] == "f16"
+        with pytest.raises(RuntimeError, match="expected fp32 or f16"):
+            with T.conv_precision("bf16"):
+                pass
+        assert T._CONV_PRECISION[0] == "f16"
+    assert T._CONV_PRECISION[0] == "fp32"
+    with pytest.raises(RuntimeError, match="precision"):
+        T.PretrainStep.__init__(object.__new__(T.PretrainStep), None, precision="half")
 
 
 def test_state_dict_surface_matches_reference_contract():
