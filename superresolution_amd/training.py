@@ -245,8 +245,51 @@ def _out(t: Optional[torch.Tensor], shape, dev) -> torch.Tensor:
     return t
 
 
+# ---- weight gradients on a second HIP stream ------------------------------------------------------------------------------
+# In a backward pass the weight gradient of a conv and everything downstream of its data gradient are independent, and
+# both chains leave most of the chip idle (staging- and latency-bound kernels, HBM-bound BatchNorm passes).  Inside
+# ``wgrad_stream(side)`` every ``conv3x3_wgrad`` call is enqueued on ``side`` (they share one scratch slab, so they must
+# stay in one queue) behind what the current stream holds so far.  A call that writes into caller-owned outputs (``p.grad``
+# views) lets the current stream go on with the data gradient at once; a call that returns fresh tensors makes the current
+# stream wait for them.  The streams are joined when the block ends.  Same kernels, same order per buffer: same results.
+_WGRAD_SIDE = [None]
+
+
+@contextlib.contextmanager
+def wgrad_stream(side: Optional["torch.cuda.Stream"]):
+    old = _WGRAD_SIDE[0]
+    _WGRAD_SIDE[0] = side
+    try:
+        yield
+    finally:
+        _WGRAD_SIDE[0] = old
+        if side is not None:
+            torch.cuda.current_stream(side.device).wait_stream(side)
+
+
 def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, ws: Workspace, dw: Optional[torch.Tensor] = None,
                   db: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """``_conv3x3_wgrad`` -- on the side stream of ``wgrad_stream`` when the outputs are the caller's."""
+    side = _WGRAD_SIDE[0]
+    if side is None:
+        return _conv3x3_wgrad(x, dy, ws, dw, db)
+    fresh = dw is None or db is None
+    dw = _out(dw, (96, 96, 3, 3), x.device)                         # (allocated on the caller's stream)
+    db = _out(db, (96,), x.device)
+    main = torch.cuda.current_stream(x.device)
+    side.wait_stream(main)                                          # dy (and its partial maxima) are ready behind this
+    with torch.cuda.stream(side):
+        out = _conv3x3_wgrad(x, dy, ws, dw, db)
+    for t in (x, dy, getattr(dy, "amax_slots", None)):              # the allocator must not hand these out before `side` is done
+        if t is not None:
+            t.record_stream(side)
+    if fresh:
+        main.wait_stream(side)                                      # the caller reads dw / db next
+    return out
+
+
+def _conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, ws: Workspace, dw: Optional[torch.Tensor] = None,
+                   db: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """(dw (96, 96, 3, 3), dbias (96,)) of ``F.conv2d(x, w, b, padding=1)`` given ``dy``; NHWC fp32 operands.  ``dw`` /
     ``db``: write into these (``p.grad`` views) instead of fresh tensors."""
     _chk_nhwc("x", x)
@@ -593,6 +636,9 @@ class PretrainStep:
         self.g = generator
         self.ws = Workspace(p0.device)
         self.optimizer = FlatAdamW(generator.parameters(), lr=lr)
+        # the 3x3 weight gradients of a backward pass run on a stream of their own beside the data-gradient chain
+        # (SRGEN_WGRAD_STREAM=0: everything on the caller's stream)
+        self.side = torch.cuda.Stream(p0.device) if os.environ.get("SRGEN_WGRAD_STREAM", "1") != "0" else None
         self.ssim_weight, self.l1_weight, self.group = ssim_weight, l1_weight, group
         self.last_metrics = None
 
@@ -639,6 +685,11 @@ class PretrainStep:
 
     # -- backward -----------------------------------------------------------------------------------------------------
     def backward(self, dsr: torch.Tensor, S: dict) -> None:
+        """Fills every ``p.grad``; on return the caller's stream holds all of them (the side stream is joined)."""
+        with wgrad_stream(self.side):
+            self._backward(dsr, S)
+
+    def _backward(self, dsr: torch.Tensor, S: dict) -> None:
         g, ws = self.g, self.ws
         P = dict(g.named_parameters())
 
@@ -647,9 +698,16 @@ class PretrainStep:
 
         # head: 9x9, 96 -> 3 (Generator.py:71), crop folded in (d out is 125 x 125)
         w = g.output[2].weight.detach()
-        r, _ = conv9x9_c3_wgrad(S["v"], dsr, ws, flip=True, want_bias=False)      # r[ci][(co,ky,kx)]
-        put("output.2.weight", r.view(96, 3, 9, 9).permute(1, 0, 2, 3).contiguous())
-        put("output.2.bias", dsr.sum(dim=(0, 2, 3)))
+        side = _WGRAD_SIDE[0]
+        if side is not None:                              # the head's weight gradient beside its data gradient
+            side.wait_stream(torch.cuda.current_stream(dsr.device))
+        with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+            r, _ = conv9x9_c3_wgrad(S["v"], dsr, ws, flip=True, want_bias=False)      # r[ci][(co,ky,kx)]
+            put("output.2.weight", r.view(96, 3, 9, 9).permute(1, 0, 2, 3).contiguous())
+            put("output.2.bias", dsr.sum(dim=(0, 2, 3)))
+        if side is not None:
+            S["v"].record_stream(side)
+            dsr.record_stream(side)
         dv = conv9x9_c3(dsr, w.permute(0, 2, 3, 1).reshape(243, 96).contiguous(), None, 128, True)
         # output[0..1]: conv3x3 at 128 x 128 + scalar PReLU (Generator.py:69-70)
         dv_pre, ds = prelu_scalar_bwd(S["v_pre"], dv, g.output[1].weight.detach(), ws)
@@ -686,6 +744,8 @@ class PretrainStep:
         # stem: x1 feeds the trunk and the long skip (gradient dm)
         dx1_pre, ds = prelu_scalar_bwd(S["x1_pre"], dcur, g.input[1].weight.detach(), ws, dy2=dm)
         put("input.1.weight", ds)
+        if side is not None:                              # (the 9x9 scratch slab was last used on the side stream)
+            torch.cuda.current_stream(dsr.device).wait_stream(side)
         r, db = conv9x9_c3_wgrad(dx1_pre, S["lr"], ws, flip=False, want_bias=True)
         put("input.0.weight", r)
         put("input.0.bias", db)
