@@ -80,7 +80,7 @@ def main():
     e = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
     step.optimizer.zero_grad()
     e[0].record()
-    with T.conv_precision(args.precision):
+    with T.conv_precision(args.precision), T.packed_weights(step.pack_jobs()):
         sr, S = step.forward(lr)
         e[1].record()
         vals = pixel_losses(sr, hr)
