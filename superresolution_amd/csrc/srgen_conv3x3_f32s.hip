@@ -404,7 +404,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32s_kernel(Conv3x3Args a, int
 #pragma unroll
                         for (int e = 0; e < 4; ++e) psum[nt][4 * G + e] = mt == 0 ? v[e] : psum[nt][4 * G + e] + v[e];
                     }
-                    *(f32x4*)(out + (size_t)(32 * mt) * PXS + 32 * nt + 8 * G) = v;
+                    if (!(ABL & 8192) || v.x == 12345.678f) *(f32x4*)(out + (size_t)(32 * mt) * PXS + 32 * nt + 8 * G) = v;
                 }
             }
         }

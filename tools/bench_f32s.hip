@@ -86,6 +86,9 @@ int main(int argc, char** argv)
         if (run<256 + 4096, false, 1>("one term, no raised priority", a, reps)) return 1;
         if (run<256 + 4, false, 1>("one term, no MFMA", a, reps)) return 1;
         if (run<256 + 16, false, 1>("one term, no global loads", a, reps)) return 1;
+        if (run<256 + 8192, false, 1>("one term, no output stores", a, reps)) return 1;
+        if (run<256 + 8192, false, 3>("three terms, no output stores", a, reps)) return 1;
+        if (run<256 + 8192 + 1, false, 1>("one term, no output stores, no pixel staging", a, reps)) return 1;
         if (run<256 + 2048, false, 1>("one term, pixel loads from L2 (image 0)", a, reps)) return 1;
         if (run<256 + 1, false, 1>("one term, no pixel staging", a, reps)) return 1;
         if (run<256 + 8, false, 1>("one term, no fragment LDS reads", a, reps)) return 1;
