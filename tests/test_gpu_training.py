@@ -400,3 +400,28 @@ def test_pretrain_step_f16_products_vs_reference_fp32_and_autocast_golden():
     assert results["auto"][0] == loss
     for k, v in results["auto"][1].items():
         assert np.array_equal(v, grads[k]), k
+
+
+def test_two_stream_backward_is_bit_identical_to_one_stream(monkeypatch):
+    """training.wgrad_stream: the weight gradients of the backward pass run on a second HIP stream beside the data-gradient
+    chain (same kernels, same order per buffer).  The flat gradient of two steps in a row must equal the single-stream
+    run's (SRGEN_WGRAD_STREAM=0) bit for bit -- a race on the shared weight-gradient scratch slab, or an operand handed back
+    to the allocator too early, shows up here."""
+    from superresolution_amd import Generator, training as T, weights as W
+    lr, hr = _step_batch()
+    flats = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SRGEN_WGRAD_STREAM", mode)
+        g = Generator()
+        g.load_state_dict(W.synthetic_state_dict(0))
+        g = g.cuda().train()
+        step = T.PretrainStep(g, lr=1e-4)
+        assert (step.side is None) == (mode == "0")
+        out = []
+        for _ in range(2):
+            step.step(lr, hr)
+            out.append(step.optimizer.flat_grad.detach().clone())
+        torch.cuda.synchronize()
+        flats[mode] = out
+    for a, b in zip(flats["0"], flats["1"]):
+        assert torch.equal(a, b)
