@@ -158,14 +158,15 @@ def training_leg(args, dev, rank, n_ranks, use_dist):
     else:
         torch.manual_seed(3)
         d = Discriminator().to(dev).train()
-        gan = GanStep(g, d, precision=args.train_precision)
+        gan = GanStep(g, d, precision=args.train_precision, reuse_forward=args.gan_reuse_forward)
         it = [0]
 
         def run():
             it[0] += 1
             return gan.step(lr, hr, update_d=(it[0] - 1) % 3 == 0)["g_loss"]      # config.py:21 discriminator_update_freq = 3
         name = (f"BASELINE.json configs[4]: GAN iteration (discriminator half-step every 3rd iteration + generator "
-                f"half-step), {n} images per GPU, fp32 tensors")
+                f"half-step), {n} images per GPU, fp32 tensors"
+                + (", generator forward of the discriminator half-step reused by the generator half-step" if args.gan_reuse_forward else ""))
         metric = "GAN iteration images/s"
 
     def barrier():
@@ -247,6 +248,9 @@ def main():
     ap.add_argument("--train-precision", choices=["fp32", "f16"], default="fp32",
                     help="cfg3 / cfg4: products of the generator's 3x3 convs -- fp32 (three f16 MFMAs per product) or f16 "
                          "(operands rounded to f16, fp32 accumulation: what the reference's bf16 autocast does to its convs)")
+    ap.add_argument("--gan-reuse-forward", action="store_true",
+                    help="cfg4: GanStep(reuse_forward=True) -- one generator forward per discriminator-updating iteration "
+                         "instead of the reference's two (same tensors bit for bit); off: the reference's schedule")
     ap.add_argument("--batch", type=int, default=BATCH, help="images per GPU per step (cfg1)")
     ap.add_argument("--cfg2-reps", type=int, default=5)
     ap.add_argument("--median-steps", type=int, default=50, help="HIP-event-timed steps of the median leg (>= 50)")

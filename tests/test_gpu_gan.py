@@ -229,3 +229,29 @@ def test_gan_step_f16_products_stays_close_to_the_fp32_step():
         cos = float(res[1] @ ref[1] / (res[1].norm() * ref[1].norm()))
         print(f"GAN iteration, {mode}: flat generator gradient vs fp32: rel {rel:.2e}, cosine {cos:.6f}")
         assert 1e-5 <= rel <= 2e-2 and cos >= 0.9998, (mode, rel, cos)
+
+
+def test_gan_step_reusing_the_forward_is_bit_identical():
+    """GanStep(reuse_forward=True): in an iteration that updates the discriminator the generator half-step takes the output
+    and saved tensors of the discriminator half-step's generator forward (same weights, same batch) instead of running it
+    again.  Losses, both flat gradients, every parameter and every BatchNorm running statistic after two iterations equal
+    the two-forward schedule bit for bit; a half-step called on its own never sees a kept forward."""
+    from superresolution_amd.gan_training import GanStep
+    res = {}
+    for reuse in (False, True):
+        g, d, _, lr, hr = _gan_setup()
+        step = GanStep(g, d, reuse_forward=reuse)
+        outs = [step.step(lr, hr, update_d=True), step.step(lr, hr, update_d=False)]
+        assert step._kept_forward is None
+        step.d_step(lr, hr)
+        assert step._kept_forward is None
+        res[reuse] = ([{k: (None if v is None else v.clone()) for k, v in o.items()} for o in outs],
+                      step.opt_g.flat_grad.clone(), step.opt_d.flat_grad.clone(),
+                      {k: v.clone() for k, v in g.state_dict().items()}, [p.detach().clone() for p in d.parameters()])
+    a, b = res[False], res[True]
+    for oa, ob in zip(a[0], b[0]):
+        for k in oa:
+            assert (oa[k] is None and ob[k] is None) or torch.equal(oa[k], ob[k]), k
+    assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert all(torch.equal(a[3][k], b[3][k]) for k in a[3])
+    assert all(torch.equal(x, y) for x, y in zip(a[4], b[4]))
