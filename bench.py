@@ -210,6 +210,16 @@ def training_leg(args, dev, rank, n_ranks, use_dist):
                           else (WINO_EXECUTED, PEAK["f32"], "conv3x3_wgrad_wino_lds_kernel + sum + final") if wpath == "wino"
                           else (1.0, PEAK["f32"], "conv3x3_wgrad_kernel + reduce"))
     flop = flop_alg * ratio
+    # HBM bytes per weight-gradient launch from the committed PMC passes of this step (tools/prof_train.sh ->
+    # profiles/r02w_pretrain_pmc.json: FETCH_SIZE x 2, the gfx950 correction for 16 B/lane reads, + WRITE_SIZE, in KB)
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02w_pretrain_pmc.json")))["f16" if f16 else "fp32"]
+        c = next(v for k, v in pmc.items() if "conv3x3_wgrad_split_kernel" in k) if wpath == "split" else None
+        if c and n == 64:
+            traffic = int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)
+    except (OSError, KeyError, StopIteration, ValueError):
+        pass
     if rank == 0:
         print(json.dumps({
             "metric": metric, "value": round(n * n_ranks * args.steps / dt, 1), "unit": "images/s", "n_gpus": n_ranks,
@@ -230,7 +240,7 @@ def training_leg(args, dev, rank, n_ranks, use_dist):
             "loss_last": float(loss),
             "roofline": {"bound": "mfma", "kernel": kname + " (38 launches per generator backward)",
                          "achieved": round(flop / (wg_ms * 1e-3) / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(flop / (wg_ms * 1e-3) / 1e12 / peak, 4), "traffic": None,
+                         "frac": round(flop / (wg_ms * 1e-3) / 1e12 / peak, 4), "traffic": traffic,
                          "ms_per_launch": round(wg_ms, 4), "flop_per_launch_executed": flop, "flop_per_launch_algorithmic": flop_alg,
                          "algorithmic_tflops": round(flop_alg / (wg_ms * 1e-3) / 1e12, 2)},
             "cpu_baseline": None}), flush=True)
