@@ -102,7 +102,8 @@ SRGEN_API int srgen_forward(srgen_handle* h, const void* x, void* y, void* works
  *                    The running-statistics update (momentum 0.1, unbiased variance = biased * m / (m - 1),
  *                    m = n * 4096) is the caller's: superresolution_amd.Generator applies it to its buffers.
  * The first call after srgen_commit_weights packs and uploads the unfolded conv weights (synchronises once).
- * The backward pass of the reference's training step is not built. */
+ * The backward pass of the training step is the "Pre-train step operators" section below; the Python mirror runs its
+ * train mode on those (superresolution_amd/training.py, autograd.py) and keeps this entry for other generator shapes. */
 SRGEN_API int srgen_forward_train(srgen_handle* h, const void* x, void* y, void* workspace,
                                   size_t workspace_bytes, int n, float* bn_batch_stats, void* stream);
 

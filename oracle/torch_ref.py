@@ -77,7 +77,7 @@ def psnr(sr, hr, max_val=1.0):
 def ssim(sr, hr, window_size=11, sigma=1.5):
     """utils.py:12-41 (zero-padded depthwise gaussian, den clamp 1e-8, global mean)."""
     c = sr.size(1)
-    coords = torch.arange(window_size, dtype=torch.float32) - window_size // 2
+    coords = torch.arange(window_size, dtype=torch.float32, device=sr.device) - window_size // 2
     g = torch.exp(-(coords ** 2) / (2 * sigma ** 2))
     g = g / g.sum()
     k = g.outer(g).view(1, 1, window_size, window_size).repeat(c, 1, 1, 1)

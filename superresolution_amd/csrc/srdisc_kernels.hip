@@ -413,7 +413,7 @@ static hipError_t launch_conv_grid(const DiscConvArgs& a, int OH, int OW, long l
     while ((1 << lg) < nst) ++lg;
     // 64 pixels per wave (16 accumulators) when that still gives every CU a workgroup, 32 otherwise
     // (small batches / the late layers)
-    static const int wide_min = getenv("SRDISC_WIDE_MIN") ? atoi(getenv("SRDISC_WIDE_MIN")) : 256;
+    constexpr int wide_min = 256;
     const bool wide = ((M + 255) / 256) * (a.Cout >> 6) >= wide_min;
     const int wg_px = wide ? 256 : 128;
     const long long blocks = ((M + wg_px - 1) / wg_px) * (a.Cout >> 6);
@@ -423,15 +423,12 @@ static hipError_t launch_conv_grid(const DiscConvArgs& a, int OH, int OW, long l
     // allow no more, and that is the fast point: at batch 256 the L2-fed layers ran 135-140 TFLOP/s that
     // way against 107-120 with two or three workgroups per CU taking turns on the matrix pipe and
     // evicting each other's weight fragments from L1; the prefetch ring hides the latency alone.
-    // (SRDISC_LDS reserves unused LDS as an occupancy limiter for experiments with the 32-pixel variant.)
-    static const int lds_env = getenv("SRDISC_LDS") ? atoi(getenv("SRDISC_LDS")) : 0;
-    const int lds_pad = lds_env;
+    const int lds_pad = 0;
     int dev = 0, cus = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (e != hipSuccess) return e;
-    static const int wg_per_cu_env = getenv("SRDISC_WGS") ? atoi(getenv("SRDISC_WGS")) : 0;
-    const int per_cu = wg_per_cu_env > 0 ? wg_per_cu_env : (wide ? 1 : 2);
+    const int per_cu = wide ? 1 : 2;
     const long long resident = (long long)cus * per_cu;
     const dim3 grid((unsigned)(blocks < resident ? blocks : resident)), block(256);
     const int ntiles = (int)blocks;

@@ -80,6 +80,8 @@ struct srgen_handle {
     // fp32 3x3 convs of the eval forward: the split-f16 kernel (default, srgen_conv3x3_f32s.hip), the Winograd
     // F(2x2,3x3) kernel on the fp32 MFMA (SRGEN_F32_CONV3X3=wino) or the direct fp32-MFMA kernel (=direct)
     bool f32_split = true;
+    bool split_amax = true;      // split path: per-image range scaling of the eval forward (SRGEN_SPLIT_NO_AMAX=1 at
+                                 // srgen_create turns it off: a test switch that shows what the scaling is for)
     bool f32_wino = false;
     // train-mode forward (srgen_forward_train): unfolded conv weights + BatchNorm affine parameters, built
     // lazily on the first train-mode call after a commit
@@ -471,6 +473,7 @@ int srgen_create(const srgen_config* cfg, srgen_handle** out)
         h->f32_split = e[0] == 0 || strcmp(e, "split") == 0;
         h->f32_wino = strcmp(e, "wino") == 0;
     }
+    if (const char* e = getenv("SRGEN_SPLIT_NO_AMAX")) h->split_amax = !(e[0] && strcmp(e, "0") != 0);
     *out = h;
     return SRGEN_OK;
 }
@@ -690,8 +693,10 @@ static int run_forward(srgen_handle* h, const void* x, void* y, void* workspace,
     // one float per image: launch L reads S[L % 3] (left by launch L - 1; the stem's output gets an absmax pass), its
     // waves accumulate the maxima of what they store into S[(L + 1) % 3] (atomic max) and it zeroes S[(L + 2) % 3] for
     // launch L + 1 to accumulate into.  Per image, so an image's result does not depend on what else is in the batch.
-    // (ChannelAttention scales in place by a sigmoid: the bound stays a bound.)
+    // ChannelAttention scales in place by a sigmoid per channel: its kernel multiplies the image's bound by the largest
+    // of them (ChanAttnArgs::amax), so the conv behind it does not scale by the un-damped maximum.
     const bool train = bn_stats != nullptr;             // (train mode: tensors behind batch-statistics BatchNorms, no chain)
+    const bool use_chain = h->split_amax;               // (SRGEN_SPLIT_NO_AMAX, a test switch, read once at srgen_create)
     int chain = 0;
     auto S = [&](int i) { return (float*)(W + ws.amax[i % 3]); };
     auto conv = [&](const ConvDev& d, const void* in, void* out, const void* res, float* pool, int H,
@@ -699,7 +704,7 @@ static int run_forward(srgen_handle* h, const void* x, void* y, void* workspace,
         Conv3x3Args a;
         a.in = in; a.out = out;
         const bool wino = !bf && h->f32_wino, split = !bf && h->f32_split;
-        if (split && !train && !getenv("SRGEN_SPLIT_NO_AMAX")) {
+        if (split && !train && use_chain) {
             a.in_amax = S(chain); a.in_amax_per_image = 1; a.out_amax = S(chain + 1); a.zero_amax = S(chain + 2);
             ++chain;
         }
@@ -779,6 +784,7 @@ static int run_forward(srgen_handle* h, const void* x, void* y, void* workspace,
             float* sc = (float*)(W + ws.scale[k]);
             ChanAttnArgs a{nxt, pool, 16, F(h->ca[k].w1), F(h->ca[k].b1), F(h->ca[k].w2), F(h->ca[k].b2),
                            sc, n, kLR * kLR};
+            if (!bf && h->f32_split && !train && use_chain) a.amax = S(chain);      // what the next conv reads
             HIP_TRY(tick(SRGEN_K_CHAN_ATTN));
             HIP_TRY(bf ? launch_chan_attn_bf16(a, s) : launch_chan_attn_f32(a, s));
             HIP_TRY(tock());
@@ -803,7 +809,7 @@ static int run_forward(srgen_handle* h, const void* x, void* y, void* workspace,
     {   // output[2] + crop                                               Generator.py:71, 80
         const bool hsplit = !bf && h->f32_split;
         HeadArgs a{v, y, B + (bf ? h->head.w_bf16 : hsplit ? h->head.w_split : h->head.w_f32), F(h->head.bias), n};
-        if (hsplit && !train && !getenv("SRGEN_SPLIT_NO_AMAX")) a.in_amax = S(chain);
+        if (hsplit && !train && use_chain) a.in_amax = S(chain);
         HIP_TRY(tick(SRGEN_K_HEAD));
         HIP_TRY(bf ? launch_head_bf16(a, s) : hsplit ? launch_head_f32_split(a, s) : launch_head_f32(a, s));
         HIP_TRY(tock());

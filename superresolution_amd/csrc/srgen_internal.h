@@ -109,6 +109,9 @@ struct ChanAttnArgs {
     float* scale_out;      // [N][96]
     int N;
     int hw;                // pixels per image (4096)
+    float* amax = nullptr; // split path, eval forward (fp32 kernel only): [N] per-image bounds of max |x| left by the conv
+                           // in front; multiplied by the image's largest channel scale, so the conv behind scales by a
+                           // bound of what it really reads (a strongly damping attention would leave the old one far too high)
 };
 
 // ---- 9x9 head, NHWC 96 in (128x128) -> NCHW 3ch out, cropped to 125x125 -----------------

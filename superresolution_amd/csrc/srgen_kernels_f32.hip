@@ -149,6 +149,13 @@ __global__ __launch_bounds__(256) void chan_attn_f32_kernel(ChanAttnArgs a)
     const int n = blockIdx.x / CA_SLICES, slice = blockIdx.x % CA_SLICES;
     ca_fc<float>(a, n, s_pool, s_hid, s_scale);
     if (slice == 0 && threadIdx.x < kC) a.scale_out[(size_t)n * kC + threadIdx.x] = s_scale[threadIdx.x];
+    if (a.amax && slice == 0 && threadIdx.x < 64) {            // |x * s| <= amax * max_c s: the refreshed per-image bound
+        const int lane = threadIdx.x;
+        float m = fmaxf(s_scale[lane], lane < 32 ? s_scale[64 + lane] : 0.f);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        if (lane == 0) a.amax[n] *= m;
+    }
     const int per_slice = a.hw * kC / 4 / CA_SLICES;          // float4 per slice
     f32x4* x = (f32x4*)a.x + (size_t)n * a.hw * kC / 4 + (size_t)slice * per_slice;
     for (int i = threadIdx.x; i < per_slice; i += 256) {

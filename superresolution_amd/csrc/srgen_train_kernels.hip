@@ -660,7 +660,7 @@ __global__ __launch_bounds__(256) void wino_wgrad_final_kernel(const float* __re
 
 static int wgrad_slices(int total_rows)
 {
-    static const int big = getenv("SRGEN_WGRAD_SLICES") ? atoi(getenv("SRGEN_WGRAD_SLICES")) : 128;
+    constexpr int big = 128;
     return total_rows < 4 * big ? (total_rows + 3) / 4 : big;
 }
 
@@ -672,7 +672,7 @@ static bool wgrad_direct()
 
 static int wgrad_lds_slices(int total_trows)
 {
-    static const int big = getenv("SRGEN_WGRAD_LDS_SLICES") ? atoi(getenv("SRGEN_WGRAD_LDS_SLICES")) : 128;
+    constexpr int big = 128;
     return total_trows < 2 * big ? (total_trows + 1) / 2 : big;
 }
 
@@ -1344,7 +1344,7 @@ __global__ __launch_bounds__(1024) void conv9x9_c3_wgrad_reduce_kernel(const flo
 // two workgroups per CU once there are rows enough (one: 1.0 ms for the head's gradient at 64 images)
 static int wgrad9_slices(int total_rows)
 {
-    static const int cap = getenv("SRGEN_WGRAD9_SLICES") ? atoi(getenv("SRGEN_WGRAD9_SLICES")) : 512;
+    constexpr int cap = 512;
     return total_rows < 4 * cap ? (total_rows + 3) / 4 : cap;
 }
 

@@ -290,9 +290,8 @@ __global__ __launch_bounds__(256, TERMS == 3 ? 1 : 2) void conv3x3_wgrad_split_k
 // workgroups (120: 179 us, 168: 154 us against 137); TERMS = 1 (two per CU): 168 slices = 504 workgroups (68 us against 73)
 int conv3x3_wgrad_split_slices(int total_rows, int terms)
 {
-    const char* e = getenv("SRGEN_WGRAD_SPLIT_SLICES");
-    int s = e ? atoi(e) & ~7 : (terms == 1 ? 168 : 80);
-    if (s < 8 || s > kWgradSplitMaxSlices) s = kWgradSplitMaxSlices;
+    int s = terms == 1 ? 168 : 80;
+    static_assert(168 <= kWgradSplitMaxSlices, "slab size");
     while (s > 8 && total_rows < s) s -= 8;
     return s;
 }

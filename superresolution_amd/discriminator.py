@@ -8,10 +8,12 @@ yields the reference's weights), ``discriminator(x)`` returning ``(N, 1, 8, 8)``
 ``125 x 125`` inputs, and ``loss.discriminator_loss(real, fake)`` / ``loss.generator_loss(real, fake)``
 returning 0-dim tensors.
 
-Scope: forward VALUES.  The reference calls these under autograd; the backward pass is not built
-(SURVEY.md 8(f) row 3 lists it as future work), so a call with gradient recording enabled on inputs
-or parameters that require grad raises instead of silently returning a graph-less tensor.  Wrap calls
-in ``torch.no_grad()``.  No eager-PyTorch or CPU fallback.
+Under ``torch.no_grad()`` the calls run the inference kernels (``srdisc_forward``).  With gradient recording on and
+parameters or inputs that require grad -- how the reference calls them (``train.py:152-156,168-174``) -- they return
+tensors whose graph is a ``torch.autograd.Function`` over the HIP backward operators (``superresolution_amd.autograd``:
+``DiscriminatorFn`` = ``gan_training.DiscriminatorGrad``, ``RaganLossFn`` = ``ragan_loss_grad``), so ``d_loss.backward()``
+and ``g_loss.backward()`` fill ``p.grad`` and carry the adversarial gradient into the generator.  Built for the reference's
+``Discriminator(in_ch=3, base_ch=64)``; other widths raise under autograd.  No eager-PyTorch or CPU fallback.
 """
 from __future__ import annotations
 
@@ -36,11 +38,20 @@ class DiscBlock(nn.Module):
                            "Discriminator itself")
 
 
-def _no_autograd(what: str, *tensors) -> None:
-    if torch.is_grad_enabled() and any(t.requires_grad for t in tensors):
-        raise NotImplementedError(
-            f"{what}: only forward values are built (no backward kernels); call it under torch.no_grad(). "
-            "There is no eager fallback.")
+def _wants_grad(*tensors) -> bool:
+    return torch.is_grad_enabled() and any(t.requires_grad for t in tensors)
+
+
+def ragan_both(r: torch.Tensor, f: torch.Tensor, real_label: float, fake_label: float) -> torch.Tensor:
+    """[discriminator_loss, generator_loss] of contiguous fp32 ROCm logits, one launch, result left on the device."""
+    out = torch.empty(2, dtype=torch.float32, device=r.device)
+    if r.numel() == 0 or f.numel() == 0:
+        return out.fill_(float("nan"))                      # mean of an empty tensor, as torch gives
+    idx = r.device.index
+    with torch.cuda.device(idx):
+        _lib.check(_lib.lib().srgen_ragan_loss(r.data_ptr(), f.data_ptr(), r.numel(), f.numel(), float(real_label),
+                                               float(fake_label), out.data_ptr(), torch.cuda.current_stream(idx).cuda_stream))
+    return out
 
 
 class Discriminator(nn.Module):
@@ -62,6 +73,7 @@ class Discriminator(nn.Module):
         self._handles: Dict[int, int] = {}
         self._weights_sig: Dict[int, Tuple] = {}
         self._workspace: Dict[int, torch.Tensor] = {}
+        self._dgrads: Dict[int, object] = {}            # device index -> gan_training.DiscriminatorGrad
 
     def _init_weights(self) -> None:                                      # Discriminator.py:42-47
         for m in self.modules():
@@ -131,7 +143,8 @@ class Discriminator(nn.Module):
             torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16)
         if x.dtype not in (torch.float32, torch.bfloat16):
             raise RuntimeError(f"unsupported input dtype {x.dtype}: fp32, or bf16 / bf16 autocast (computed in fp32)")
-        _no_autograd("Discriminator.forward", x, *self.parameters())
+        if taps is None and _wants_grad(x, *self.parameters()):
+            return self._run_autograd(x, bf16_out)
         xc = x.detach().float().contiguous()
         n, _, hgt, wid = xc.shape
         idx = xc.device.index
@@ -166,16 +179,37 @@ class Discriminator(nn.Module):
                                         arr, stream), "Discriminator")
         return y.to(torch.bfloat16) if bf16_out else y
 
+    def _run_autograd(self, x: torch.Tensor, bf16_out: bool) -> torch.Tensor:
+        """Logits with a graph (train.py:152-153,168): forward with saved activations from the live parameters,
+        ``autograd.DiscriminatorFn`` behind it."""
+        from . import autograd as A
+        from .gan_training import DiscriminatorGrad
+        from .training import Workspace
+        if self.base_ch != 64 or self.in_ch != 3:
+            raise NotImplementedError("Discriminator.forward under autograd: the backward operators are built for the "
+                                      "reference's Discriminator(in_ch=3, base_ch=64); other widths run forward values "
+                                      "under torch.no_grad(). There is no eager fallback.")
+        idx = x.device.index
+        dg = self._dgrads.get(idx)
+        if dg is None:
+            dg = self._dgrads[idx] = DiscriminatorGrad(self, Workspace(x.device))
+        names = [k for k, _ in self.named_parameters()]
+        params = [p for _, p in self.named_parameters()]
+        with torch.cuda.device(idx):
+            y = A.DiscriminatorFn.apply(dg, names, x if x.dtype == torch.float32 else x.float(), *params)
+        return y.to(torch.bfloat16) if bf16_out else y
+
     # ---- module protocol -------------------------------------------------------------------
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)
         self._weights_sig.clear()
         self._workspace.clear()
+        self._dgrads.clear()
         return out
 
     def __getstate__(self):
         state = self.__dict__.copy()
-        state["_handles"], state["_weights_sig"], state["_workspace"] = {}, {}, {}
+        state["_handles"], state["_weights_sig"], state["_workspace"], state["_dgrads"] = {}, {}, {}, {}
         return state
 
     def __del__(self):
@@ -198,7 +232,8 @@ class RelativisticAverageLoss(nn.Module):
         self.real_label = real_label
         self.fake_label = fake_label
 
-    def _both(self, real: torch.Tensor, fake: torch.Tensor) -> torch.Tensor:
+    @staticmethod
+    def _check(real: torch.Tensor, fake: torch.Tensor) -> None:
         for nm, t in (("real", real), ("fake", fake)):
             if not isinstance(t, torch.Tensor) or not t.is_cuda:
                 raise RuntimeError(f"RelativisticAverageLoss: `{nm}` must be a tensor on a ROCm device; there is "
@@ -207,25 +242,28 @@ class RelativisticAverageLoss(nn.Module):
                 raise RuntimeError(f"RelativisticAverageLoss: `{nm}` is {t.dtype}; fp32 or bf16 logits (computed in fp32)")
         if real.device != fake.device:
             raise RuntimeError(f"real is on {real.device}, fake on {fake.device}")
-        _no_autograd("RelativisticAverageLoss", real, fake)
+
+    def _both(self, real: torch.Tensor, fake: torch.Tensor) -> torch.Tensor:
+        self._check(real, fake)
         r, f = real.detach().float().contiguous(), fake.detach().float().contiguous()   # BCEWithLogits autocasts to fp32
-        out = torch.empty(2, dtype=torch.float32, device=r.device)
-        if r.numel() == 0 or f.numel() == 0:
-            return out.fill_(float("nan"))                  # mean of an empty tensor, as torch gives
-        idx = r.device.index
-        with torch.cuda.device(idx):
-            _lib.check(_lib.lib().srgen_ragan_loss(r.data_ptr(), f.data_ptr(), r.numel(), f.numel(),
-                                                   float(self.real_label), float(self.fake_label),
-                                                   out.data_ptr(), torch.cuda.current_stream(idx).cuda_stream))
-        return out
+        return ragan_both(r, f, self.real_label, self.fake_label)
+
+    def _one(self, real: torch.Tensor, fake: torch.Tensor, which: int) -> torch.Tensor:
+        if _wants_grad(real, fake):                         # train.py:154-156,169-174: the loss is differentiated
+            from . import autograd as A
+            self._check(real, fake)
+            if real.numel() == 0 or fake.numel() == 0:
+                raise RuntimeError("RelativisticAverageLoss under autograd needs non-empty logits")
+            return A.RaganLossFn.apply(real, fake, float(self.real_label), float(self.fake_label), which)
+        return self._both(real, fake)[which]
 
     def discriminator_loss(self, real: torch.Tensor, fake: torch.Tensor) -> torch.Tensor:
-        return self._both(real, fake)[0]
+        return self._one(real, fake, 0)
 
     def generator_loss(self, real: torch.Tensor, fake: torch.Tensor) -> torch.Tensor:
-        return self._both(real, fake)[1]
+        return self._one(real, fake, 1)
 
     def both_losses(self, real: torch.Tensor, fake: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-        """(discriminator_loss, generator_loss) from one launch (no counterpart in the reference)."""
+        """(discriminator_loss, generator_loss) from one launch (no counterpart in the reference); forward values."""
         o = self._both(real, fake)
         return o[0], o[1]

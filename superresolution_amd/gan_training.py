@@ -22,7 +22,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from . import _lib
-from .training import FlatAdamW, PretrainStep, Workspace, conv_precision, packed_weights, pixel_loss_grad, resolve_precision
+from .training import FlatAdamW, PretrainStep, Workspace, allreduce_mean, conv_precision, packed_weights, pixel_loss_grad, resolve_precision
 
 SLOPE = 0.2                                  # nn.LeakyReLU(0.2), Discriminator.py:10,24,36
 
@@ -135,14 +135,22 @@ class DiscriminatorGrad:
                 p.grad = torch.zeros_like(p)
         return conv.weight.grad, conv.bias.grad
 
-    def backward(self, dlogits: torch.Tensor, saved: dict, want_wgrad: bool = True, want_dimg: bool = False) -> Optional[torch.Tensor]:
+    def backward(self, dlogits: torch.Tensor, saved: dict, want_wgrad: bool = True, want_dimg: bool = False,
+                 into: Optional[Dict[str, torch.Tensor]] = None) -> Optional[torch.Tensor]:
+        """``into``: {state_dict key -> contiguous fp32 tensor} the weight / bias gradients are WRITTEN to (the autograd
+        wrapper hands them to torch, which accumulates); default: ADDED to ``p.grad``, as ``loss.backward()`` would."""
         L, ws = _lib.lib(), self.ws
         acts, sizes, xc = saved["acts"], saved["sizes"], saved["x"]
         n = xc.shape[0]
         dl = dlogits.detach().to(torch.float32).contiguous()
         need = ctypes.c_size_t()
+        key_of = {id(p): k for k, p in self.d.named_parameters()} if into is not None else None
 
         def put(conv, dw, db):                     # accumulate, as autograd does into .grad
+            if into is not None:
+                into[key_of[id(conv.weight)]].copy_(dw.view_as(conv.weight))
+                into[key_of[id(conv.bias)]].copy_(db.view_as(conv.bias))
+                return
             gw, gb = self._grad_views(conv)
             gw.add_(dw)
             gb.add_(db)
@@ -230,14 +238,7 @@ class GanStep:
         self.last_grad_norm = None
 
     def _allreduce(self, buf: torch.Tensor) -> None:
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
-            if dist.get_backend(self.group) != "nccl":
-                # host-staged backends (gloo) read the buffer on the CPU side; with the backward still in flight on the
-                # stream a two-rank run on one GPU hung inside the collective one time in three (tests/test_gpu_training_dp.py)
-                torch.cuda.current_stream(buf.device).synchronize()
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
-            buf.div_(dist.get_world_size(self.group))
+        allreduce_mean(buf, self.group)
 
     def _ragan(self, real: torch.Tensor, fake: torch.Tensor) -> torch.Tensor:
         out = torch.empty(2, dtype=torch.float32, device=real.device)

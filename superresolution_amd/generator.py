@@ -9,9 +9,14 @@ order, ``.to() / .eval() / .train() / .parameters()``, and ``generator(x)`` retu
 The sub-modules are stock ``torch.nn`` layers used purely as parameter containers; nothing
 here ever calls their ``forward``.  ``Generator.forward`` hands the input, an output tensor
 and a workspace to ``libsrgen.so`` (``include/srgen.h``) on the current HIP stream.  There
-is no eager-PyTorch or CPU fallback: a CPU tensor or a missing extension raises.  The returned
-tensor never carries an autograd graph (the backward pass is not built): train mode under autograd,
-or an eval-mode input that requires grad, raise instead of silently yielding no gradient.
+is no eager-PyTorch or CPU fallback: a CPU tensor or a missing extension raises.
+
+Train mode (``train.py:92,149,167``) runs the HIP training operators of ``superresolution_amd.training``: batch-statistics
+BatchNorm, running-statistics update, and -- with gradient recording on -- a ``torch.autograd.Function``
+(``superresolution_amd.autograd``) whose backward fills ``p.grad`` through the HIP backward operators, so the reference's
+``loss.backward(); optimizer.step()`` runs unchanged.  What is not built raises instead of silently yielding no gradient:
+the gradient w.r.t. the INPUT image (train or eval mode; the reference never asks for it), and parameter gradients of
+the eval-mode forward (folded BatchNorm; the reference never trains in eval mode).
 """
 from __future__ import annotations
 
@@ -83,6 +88,10 @@ class Generator(nn.Module):
         self._handles: Dict[int, int] = {}            # device index -> srgen_handle*
         self._weights_sig: Dict[int, Tuple] = {}       # device index -> signature of uploaded weights
         self._workspace: Dict[Tuple[int, int], torch.Tensor] = {}
+        self._engines: Dict[int, object] = {}          # device index -> training.GeneratorGrad (train-mode operators)
+        # 3x3 conv products of the train-mode forward / backward: "auto" = f16 products inside torch.autocast with a
+        # 16-bit dtype (how train.py:91,148,166 call the generator), fp32 products otherwise; or "fp32" / "f16"
+        self.train_precision = "auto"
 
     # ---- HIP handle / weights ----------------------------------------------------------
     def _signature(self) -> Tuple:
@@ -136,17 +145,12 @@ class Generator(nn.Module):
 
     # ---- forward -------------------------------------------------------------------------
     def _prepare(self, x: torch.Tensor):
-        if self.training and torch.is_grad_enabled() and (
-                x.requires_grad or any(p.requires_grad for p in self.parameters())):
+        if torch.is_grad_enabled() and isinstance(x, torch.Tensor) and x.requires_grad:
             raise NotImplementedError(
-                "Generator.forward in train mode under autograd (train.py:92,149,167): the backward pass is not "
-                "built. Train-mode forward VALUES (batch-statistics BatchNorm, running-statistics update) run "
-                "under torch.no_grad(); for inference call .eval(). There is no eager fallback.")
-        if not self.training and torch.is_grad_enabled() and isinstance(x, torch.Tensor) and x.requires_grad:
-            raise NotImplementedError(
-                "Generator.forward in eval mode with an input that requires grad: the backward pass is not built, "
-                "and the HIP forward returns a tensor with no autograd graph (it would silently give no gradient). "
-                "Detach the input or call under torch.no_grad().")
+                "Generator.forward with an input that requires grad: the gradient w.r.t. the input image is not built "
+                "(the reference never asks for it: lr comes from the data loader, train.py:88,143), and silently giving "
+                "none would be wrong. Parameter gradients come from .train() mode (superresolution_amd/autograd.py); "
+                "otherwise detach the input or call under torch.no_grad().")
         if not isinstance(x, torch.Tensor) or x.dim() != 4:
             raise RuntimeError(f"Expected 4D (N, {self.in_ch}, 64, 64) input, got {tuple(getattr(x, 'shape', ()))}")
         if x.shape[1] != self.in_ch:
@@ -171,8 +175,50 @@ class Generator(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if self.training:
+            if (self.num_blocks, self.in_ch, self.base_ch) == (16, 3, 96):
+                return self._run_train_ops(x)
+            if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+                raise NotImplementedError(
+                    "Generator.forward in train mode under autograd: the backward operators are built for the reference's "
+                    "Generator(num_blocks=16, in_ch=3, base_ch=96) only; other shapes run train-mode forward VALUES under "
+                    "torch.no_grad(). There is no eager fallback.")
             return self._run_train(x)
         return self._run(x, None)
+
+    def _engine(self, device: torch.device):
+        from . import training as T
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        e = self._engines.get(idx)
+        if e is None:
+            e = self._engines[idx] = T.GeneratorGrad(self)
+        return e
+
+    def _run_train_ops(self, x: torch.Tensor) -> torch.Tensor:
+        """Train-mode forward on the training operators (``training.GeneratorGrad``; the reference's call sites
+        train.py:92,149,167): batch-statistics BatchNorm from the LIVE parameters (weight images are made on the device, so
+        an optimizer step costs no host re-upload), running statistics updated as ``nn.BatchNorm2d`` does.  With gradient
+        recording on, the result carries a graph whose backward is the HIP backward pass (``autograd.GeneratorTrainFn``).
+        Tensors are fp32; under ``torch.autocast(bfloat16)`` (or with a bf16 input) the 3x3 conv products are 16-bit
+        (``train_precision``) and the output is rounded to bf16 once, as the reference's autocast returns it."""
+        from . import autograd as A, training as T
+        xc, code, dt = self._prepare(x)
+        if xc.shape[0] == 0:
+            raise ValueError("Expected more than 1 value per channel when training, got an empty batch")
+        if self.train_precision not in ("auto", "fp32", "f16"):
+            raise RuntimeError(f"train_precision '{self.train_precision}': expected auto, fp32 or f16")
+        precision = T.resolve_precision(self.train_precision)
+        if self.train_precision == "auto" and code != _lib.SRGEN_F32 and T.conv_path() == "split":
+            precision = "f16"                                  # a bf16 input outside autocast: same 16-bit arithmetic
+        engine = self._engine(xc.device)
+        with torch.cuda.device(xc.device):
+            if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+                y = A.generator_train_forward(self, engine, xc.float(), precision)
+            else:
+                with T.conv_precision(precision), T.packed_weights(engine.pack_jobs(backward=False)):
+                    y, S = engine.forward(xc.float())
+                engine._update_running_stats(S, y.shape[0])
+                del S
+        return y if dt == torch.float32 else y.to(dt)
 
     def _bn_modules(self):
         """The BatchNorm2d layers in module order (= the order of srgen_forward_train's bn_batch_stats)."""
@@ -270,12 +316,13 @@ class Generator(nn.Module):
         out = super()._apply(fn, *a, **k)
         self._weights_sig.clear()          # parameters moved / cast: re-upload on next forward
         self._workspace.clear()
+        self._engines.clear()
         return out
 
     def __getstate__(self):
         # pickling / deepcopy must not share (and later double-free) the library handles
         state = self.__dict__.copy()
-        state["_handles"], state["_weights_sig"], state["_workspace"] = {}, {}, {}
+        state["_handles"], state["_weights_sig"], state["_workspace"], state["_engines"] = {}, {}, {}, {}
         return state
 
     def __del__(self):

@@ -169,16 +169,19 @@ _PACKED = {}
 
 
 @contextlib.contextmanager
-def packed_weights(jobs):
+def packed_weights(jobs, outs=None):
+    """``outs``: images a former ``packed_weights(jobs)`` block made (it yields them) -- installed again without packing,
+    e.g. by a backward pass that runs after the block of its forward has ended."""
     if conv_path() != "split" or not jobs:
-        yield
+        yield None
         return
-    outs = split_pack_many(jobs)
+    if outs is None:
+        outs = split_pack_many(jobs)
     old = dict(_PACKED)
     for (w, mode, block), o in zip(jobs, outs):
         _PACKED[(w.data_ptr(), mode, block)] = o
     try:
-        yield
+        yield outs
     finally:
         _PACKED.clear()
         _PACKED.update(old)
@@ -606,41 +609,35 @@ def chan_attn_backward(dy: torch.Tensor, saved: dict, ca: torch.nn.Module, ws: W
     return dx, g
 
 
+def allreduce_mean(buf: torch.Tensor, group=None) -> None:
+    """Data-parallel gradient averaging: ONE all-reduce (SUM, then / world size) of a flat gradient buffer, enqueued on the
+    caller's stream behind the backward pass that fills it -- the same code for RCCL ("nccl") and for host-staged backends
+    (gloo stages through pinned memory on a stream of its own behind an event of the caller's stream).  No-op outside
+    ``torch.distributed`` or with one rank."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+        buf.div_(dist.get_world_size(group))
+
+
 # ---- the whole generator: forward in train mode with saved tensors, backward, optimizer step ------------------------------
-class PretrainStep:
-    """One pre-train step of the reference (``train.py:90-97``) for the drop-in ``Generator`` on one GPU:
+class GeneratorGrad:
+    """Train-mode forward of the drop-in ``Generator`` with the tensors its backward needs, and that backward, composed from
+    the HIP operators above (``Generator.py:45-80`` under ``train.py:92-94``).  ``backward`` writes every parameter gradient
+    into tensors the caller names (``p.grad`` views of a flat buffer for ``PretrainStep``; a fresh flat buffer for the
+    ``torch.autograd.Function`` behind ``Generator.forward``, superresolution_amd/autograd.py)."""
 
-        sr = generator(lr)                                  # train mode: batch-statistics BatchNorm (Generator.py:74-80)
-        loss = weighted_l1(sr, hr) + 0.1 * (1 - ssim(sr, hr))
-        loss.backward(); optimizer.step()                   # AdamW(lr 1e-4), train.py:270
-
-    composed from the HIP operators above; gradients land in ``p.grad`` (views of ``optimizer.flat_grad``, so the
-    reference's ``grad_norm`` (train.py:23-28) and a data-parallel all-reduce of ONE 12.86 MB buffer work unchanged),
-    BatchNorm running statistics are updated as ``nn.BatchNorm2d`` does.  Tensors are fp32; ``precision`` picks the 3x3
-    conv products: "fp32", "f16" (16-bit operands, fp32 accumulation: what the reference's bf16 autocast does to its
-    convs) or "auto" (default: "f16" when ``step`` is called inside ``torch.autocast`` with a 16-bit dtype, as train.py:91
-    calls the generator, else "fp32"; see ``conv_precision``).  With
-    ``world_size > 1`` (one process per GPU, ``torch.distributed`` initialised) ``step`` averages ``flat_grad`` over the
-    ranks with one all-reduce before the update, as DistributedDataParallel would."""
-
-    def __init__(self, generator, lr: float = 1e-4, ssim_weight: float = 0.1, l1_weight: float = 1.0, group=None,
-                 precision: str = "auto"):
-        if precision not in ("auto", "fp32", "f16"):
-            raise RuntimeError(f"precision '{precision}': expected auto, fp32 or f16")
-        self.precision = precision
+    def __init__(self, generator):
         p0 = next(generator.parameters())
         if not p0.is_cuda:
-            raise RuntimeError("PretrainStep needs the generator on a ROCm device; there is no CPU fallback")
+            raise RuntimeError("the training operators need the generator on a ROCm device; there is no CPU fallback")
         if generator.num_blocks != 16 or generator.base_ch != 96 or generator.in_ch != 3:
             raise NotImplementedError("the training operators are built for Generator(16, 3, 96)")
         self.g = generator
         self.ws = Workspace(p0.device)
-        self.optimizer = FlatAdamW(generator.parameters(), lr=lr)
         # the 3x3 weight gradients of a backward pass run on a stream of their own beside the data-gradient chain
         # (SRGEN_WGRAD_STREAM=0: everything on the caller's stream)
         self.side = torch.cuda.Stream(p0.device) if os.environ.get("SRGEN_WGRAD_STREAM", "1") != "0" else None
-        self.ssim_weight, self.l1_weight, self.group = ssim_weight, l1_weight, group
-        self.last_metrics = None
 
     def pack_jobs(self, backward: bool = True) -> list:
         """(weight, mode, block) of every 3x3 weight image a step uses: forward images, and the data-gradient images."""
@@ -684,17 +681,24 @@ class PretrainStep:
         return y, S
 
     # -- backward -----------------------------------------------------------------------------------------------------
-    def backward(self, dsr: torch.Tensor, S: dict) -> None:
-        """Fills every ``p.grad``; on return the caller's stream holds all of them (the side stream is joined)."""
+    def backward(self, dsr: torch.Tensor, S: dict, G: Optional[Dict[str, torch.Tensor]] = None) -> None:
+        """Writes the gradient of every parameter into ``G[name]`` (contiguous fp32 tensors of the parameters' shapes;
+        default: the parameters' ``.grad``); on return the caller's stream holds all of them (the side stream is joined)."""
+        if G is None:
+            G = {}
+            for k, p in self.g.named_parameters():
+                if p.grad is None:
+                    raise RuntimeError(f"{k}.grad is None: the step writes into the gradient views its optimizer made "
+                                       "(zero_grad(set_to_none=True) on the module drops them; use optimizer.zero_grad())")
+                G[k] = p.grad
         with wgrad_stream(self.side):
-            self._backward(dsr, S)
+            self._backward(dsr, S, G)
 
-    def _backward(self, dsr: torch.Tensor, S: dict) -> None:
+    def _backward(self, dsr: torch.Tensor, S: dict, G: Dict[str, torch.Tensor]) -> None:
         g, ws = self.g, self.ws
-        P = dict(g.named_parameters())
 
         def put(key, grad):
-            P[key].grad.copy_(grad.view_as(P[key]))
+            G[key].copy_(grad.view_as(G[key]))
 
         # head: 9x9, 96 -> 3 (Generator.py:71), crop folded in (d out is 125 x 125)
         w = g.output[2].weight.detach()
@@ -712,7 +716,7 @@ class PretrainStep:
         # output[0..1]: conv3x3 at 128 x 128 + scalar PReLU (Generator.py:69-70)
         dv_pre, ds = prelu_scalar_bwd(S["v_pre"], dv, g.output[1].weight.detach(), ws)
         put("output.1.weight", ds)
-        conv3x3_wgrad(S["u"], dv_pre, ws, P["output.0.weight"].grad, P["output.0.bias"].grad)
+        conv3x3_wgrad(S["u"], dv_pre, ws, G["output.0.weight"], G["output.0.bias"])
         du = conv3x3(dv_pre, conv_pack(g.output[0].weight, mode=1), scale_input=True)
         # upsample: conv 96 -> 384, PixelShuffle(2), scalar PReLU (Generator.py:4-12)
         up = g.upsample
@@ -720,7 +724,7 @@ class PretrainStep:
         put("upsample.act.weight", ds)
         n = du_pre.shape[0]
         planes = du_pre.view(n, 64, 2, 64, 2, 96).permute(2, 4, 0, 1, 3, 5).contiguous()     # [i][j] -> (n, 64, 64, 96)
-        gw, gb = P["upsample.conv.weight"].grad.view(96, 4, 96, 3, 3), P["upsample.conv.bias"].grad.view(96, 4)
+        gw, gb = G["upsample.conv.weight"].view(96, 4, 96, 3, 3), G["upsample.conv.bias"].view(96, 4)
         dm = None
         for b in range(4):
             pl = planes[b >> 1, b & 1]
@@ -730,14 +734,14 @@ class PretrainStep:
             dm = conv3x3(pl, conv_pack(up.conv.weight, mode=1, block=b), res=dm, scale_input=True)
         # mid conv + BatchNorm, long skip x1 + x3 (Generator.py:61-64,78)
         dc, _, _, _ = bn_train_bwd(S["mid_c"], dm, S["mid_st"], g.mid[1].weight.detach(), g.mid[1].bias.detach(), ws,
-                                   dgamma=P["mid.1.weight"].grad, dbeta=P["mid.1.bias"].grad)
-        conv3x3_wgrad(S["mid_in"], dc, ws, P["mid.0.weight"].grad, P["mid.0.bias"].grad)
+                                   dgamma=G["mid.1.weight"], dbeta=G["mid.1.bias"])
+        conv3x3_wgrad(S["mid_in"], dc, ws, G["mid.0.weight"], G["mid.0.bias"])
         dcur = conv3x3(dc, conv_pack(g.mid[0].weight, mode=1), scale_input=True)
         # trunk, last module first (Generator.py:55-59)
         for idx in range(len(g.blocks) - 1, -1, -1):
             m, saved = g.blocks[idx], S["blocks"][idx]
-            into = {k[len(f"blocks.{idx}."):]: p.grad for k, p in P.items() if k.startswith(f"blocks.{idx}.")}
-            if hasattr(m, "block"):                       # gradients are written straight into the p.grad views
+            into = {k[len(f"blocks.{idx}."):]: t for k, t in G.items() if k.startswith(f"blocks.{idx}.")}
+            if hasattr(m, "block"):                       # gradients are written straight into the caller's tensors
                 dcur, _ = resblock_backward(dcur, saved, m, ws, into)
             else:
                 dcur, _ = chan_attn_backward(dcur, saved, m, ws, into)
@@ -761,6 +765,36 @@ class PretrainStep:
             torch._foreach_add_(varis, [st[1] for st in S["stats"]], alpha=0.1 * m / max(m - 1, 1))
             torch._foreach_add_([bn.num_batches_tracked for bn in bns], 1)
 
+
+
+class PretrainStep(GeneratorGrad):
+    """One pre-train step of the reference (``train.py:90-97``) for the drop-in ``Generator`` on one GPU:
+
+        sr = generator(lr)                                  # train mode: batch-statistics BatchNorm (Generator.py:74-80)
+        loss = weighted_l1(sr, hr) + 0.1 * (1 - ssim(sr, hr))
+        loss.backward(); optimizer.step()                   # AdamW(lr 1e-4), train.py:270
+
+    as ONE call with no autograd graph (the reference's own loop body also runs unchanged on the drop-in modules, through
+    superresolution_amd/autograd.py; this object is the fused form: loss and loss gradient from two kernels, gradients
+    written straight into one flat buffer).  Gradients land in ``p.grad`` (views of ``optimizer.flat_grad``, so the
+    reference's ``grad_norm`` (train.py:23-28) and a data-parallel all-reduce of ONE 12.86 MB buffer work unchanged),
+    BatchNorm running statistics are updated as ``nn.BatchNorm2d`` does.  Tensors are fp32; ``precision`` picks the 3x3
+    conv products: "fp32", "f16" (16-bit operands, fp32 accumulation: what the reference's bf16 autocast does to its
+    convs) or "auto" (default: "f16" when ``step`` is called inside ``torch.autocast`` with a 16-bit dtype, as train.py:91
+    calls the generator, else "fp32"; see ``conv_precision``).  With
+    ``world_size > 1`` (one process per GPU, ``torch.distributed`` initialised) ``step`` averages ``flat_grad`` over the
+    ranks with one all-reduce before the update, as DistributedDataParallel would."""
+
+    def __init__(self, generator, lr: float = 1e-4, ssim_weight: float = 0.1, l1_weight: float = 1.0, group=None,
+                 precision: str = "auto"):
+        if precision not in ("auto", "fp32", "f16"):
+            raise RuntimeError(f"precision '{precision}': expected auto, fp32 or f16")
+        self.precision = precision
+        super().__init__(generator)
+        self.optimizer = FlatAdamW(generator.parameters(), lr=lr)
+        self.ssim_weight, self.l1_weight, self.group = ssim_weight, l1_weight, group
+        self.last_metrics = None
+
     def forward_backward(self, lr_img: torch.Tensor, hr_img: torch.Tensor) -> torch.Tensor:
         """Fills every ``p.grad`` and returns the loss (0-dim device tensor)."""
         from .functional import pixel_losses
@@ -778,15 +812,8 @@ class PretrainStep:
         return loss
 
     def step(self, lr_img: torch.Tensor, hr_img: torch.Tensor) -> torch.Tensor:
-        import torch.distributed as dist
         self.optimizer.zero_grad()
         loss = self.forward_backward(lr_img, hr_img)
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
-            if dist.get_backend(self.group) != "nccl":
-                # host-staged backends (gloo) read the buffer on the CPU side; with the backward still in flight on the
-                # stream a two-rank run on one GPU was seen to hang inside the collective (tests/test_gpu_training_dp.py)
-                torch.cuda.current_stream(self.optimizer.flat_grad.device).synchronize()
-            dist.all_reduce(self.optimizer.flat_grad, op=dist.ReduceOp.SUM, group=self.group)       # 12.86 MB, one collective
-            self.optimizer.flat_grad.div_(dist.get_world_size(self.group))
+        allreduce_mean(self.optimizer.flat_grad, self.group)                    # 12.86 MB, one collective
         self.optimizer.step()
         return loss

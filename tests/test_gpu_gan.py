@@ -111,17 +111,8 @@ def _gan_setup():
     return g, d, GanStep(g, d), lr, hr
 
 
-def test_gan_step_vs_reference_golden():
-    """One GAN iteration of the REAL reference (make_golden_gan.py): discriminator loss / logits / gradients, the
-    adversarial gradient at the fake image, the generator's loss terms, its total gradient norm and clipped gradients."""
-    from superresolution_amd.gan_training import ragan_loss_grad
-    gs = np.load(os.path.join(GOLDEN, "gan_step.npz"))
-    g, d, step, lr, hr = _gan_setup()
-    # -- discriminator step
-    d_loss, real_logits = step.d_step(lr, hr)
-    assert abs(float(d_loss) - float(gs["d_loss"])) <= 1e-5 * abs(float(gs["d_loss"]))
-    assert max_rel(real_logits.cpu().numpy(), gs["real_logits"]) <= 1e-4
-    P = dict(d.named_parameters())
+def _check_disc_grads_vs_golden(P, gs):
+    """``P``: {name -> gradient} of the discriminator after the discriminator half-step, against gan_step.npz."""
     assert list(P) == [str(k) for k in gs["d_keys"]]
     # One LeakyReLU sign flip between two fp32 computations (see the adversarial-gradient test below) moves the bias /
     # weight gradient of its channel -- a sum of 256 (last layers) to 31,000 signed terms -- by up to a few percent of
@@ -130,7 +121,7 @@ def test_gan_step_vs_reference_golden():
     # beyond 5e-2.  The same backward on identical inputs is held to 2e-5 in test_discriminator_backward_vs_torch_autograd.
     errs = []
     for i, k in enumerate(P):
-        gr = P[k].grad.detach().double().cpu()
+        gr = P[k].detach().double().cpu()
         ref_sum, ref_sq, ref_max = gs["d_grad_sums"][i]
         if k == "head.2.bias":
             # = sum of dL/dlogits over real and fake, which is exactly 0 for the relativistic-average loss (each mean
@@ -144,17 +135,15 @@ def test_gan_step_vs_reference_golden():
     errs = np.concatenate(errs)
     print("GAN step: discriminator gradient samples: max", errs.max(), "99th percentile", np.quantile(errs, 0.99), "of", errs.size)
     assert np.quantile(errs, 0.99) <= STEP_TOL and errs.max() <= 5e-2
-    # -- generator step (the discriminator has just been updated, as in the reference)
-    stats = step.g_step(lr, hr, real_logits)
-    for k in ("g_adv", "g_pix", "g_ssim", "g_loss"):
-        assert abs(float(stats[k]) - float(gs[k])) <= 2e-5 * abs(float(gs[k])), (k, float(stats[k]), float(gs[k]))
-    assert abs(float(step.last_grad_norm) - float(gs["g_grad_norm"])) <= 1e-3 * float(gs["g_grad_norm"])
-    G = dict(g.named_parameters())
+
+
+def _check_gen_grads_vs_golden(G, gs):
+    """``G``: {name -> clipped gradient} of the generator after the generator half-step, against gan_step.npz."""
     assert list(G) == [str(k) for k in gs["g_keys"]]
     scale_all = float(gs["g_grad_sums"][:, 2].max())
     worst = 0.0
     for i, k in enumerate(G):
-        gr = G[k].grad.detach().double().cpu()
+        gr = G[k].detach().double().cpu()
         ref_sum, ref_sq, ref_max = gs["g_grad_sums"][i]
         if k.endswith((".block.0.bias", ".block.3.bias")) or k == "mid.0.bias":     # true gradient 0 (BatchNorm behind it)
             assert float(gr.abs().max()) <= 1e-4 * scale_all, k
@@ -168,8 +157,101 @@ def test_gan_step_vs_reference_golden():
             worst = max(worst, e)
             assert e <= STEP_TOL, (k, e)
     print("GAN step: worst generator gradient error (after clipping)", worst)
+
+
+def test_gan_step_vs_reference_golden():
+    """One GAN iteration of the REAL reference (make_golden_gan.py): discriminator loss / logits / gradients, the
+    adversarial gradient at the fake image, the generator's loss terms, its total gradient norm and clipped gradients."""
+    gs = np.load(os.path.join(GOLDEN, "gan_step.npz"))
+    g, d, step, lr, hr = _gan_setup()
+    # -- discriminator step
+    d_loss, real_logits = step.d_step(lr, hr)
+    assert abs(float(d_loss) - float(gs["d_loss"])) <= 1e-5 * abs(float(gs["d_loss"]))
+    assert max_rel(real_logits.cpu().numpy(), gs["real_logits"]) <= 1e-4
+    _check_disc_grads_vs_golden({k: p.grad for k, p in d.named_parameters()}, gs)
+    # -- generator step (the discriminator has just been updated, as in the reference)
+    stats = step.g_step(lr, hr, real_logits)
+    for k in ("g_adv", "g_pix", "g_ssim", "g_loss"):
+        assert abs(float(stats[k]) - float(gs[k])) <= 2e-5 * abs(float(gs[k])), (k, float(stats[k]), float(gs[k]))
+    assert abs(float(step.last_grad_norm) - float(gs["g_grad_norm"])) <= 1e-3 * float(gs["g_grad_norm"])
+    _check_gen_grads_vs_golden({k: p.grad for k, p in g.named_parameters()}, gs)
     # the discriminator after its AdamW update
     assert max_rel(step.real_logits(hr).cpu().numpy(), gs["real_logits_after"]) <= 1e-4
+
+
+def test_reference_gan_loop_body_runs_on_the_dropin_modules():
+    """train.py:145-176 verbatim (one iteration that updates the discriminator) on ``superresolution_amd.Generator`` /
+    ``Discriminator`` / ``RelativisticAverageLoss`` with STOCK ``torch.optim.AdamW`` and ``torch.nn.utils.clip_grad_norm_``:
+    ``d_loss.backward()`` and ``g_loss.backward()`` reach the HIP backward operators through superresolution_amd/autograd.py.
+    Run without autocast = the fp32 iteration of the real reference in gan_step.npz: same bars as GanStep's own test.
+    ``weighted_l1`` as train.py:18-20 defines it; ``ssim`` = the stock-torch restatement of utils.py:21-41."""
+    from oracle import torch_ref as TR
+    from superresolution_amd import Discriminator, Generator, RelativisticAverageLoss, weights as W
+    gs = np.load(os.path.join(GOLDEN, "gan_step.npz"))
+    generator = Generator()
+    generator.load_state_dict(W.synthetic_state_dict(0))
+    generator = generator.cuda()
+    torch.manual_seed(3)
+    discriminator = Discriminator().cuda()
+    opt_g = torch.optim.AdamW(generator.parameters(), lr=1e-4)                 # train.py:274-275, config.py:11-12
+    opt_d = torch.optim.AdamW(discriminator.parameters(), lr=1e-6)
+    criterion = RelativisticAverageLoss()                                       # train.py:128
+    generator.train()
+    discriminator.train()
+    lr = torch.from_numpy(W.synthetic_lr_batch(2, 2, "dense")).cuda()
+    hr = torch.from_numpy(W.synthetic_hr_batch(2, seed=1)).cuda()
+
+    def weighted_l1(sr, hr):                                                    # train.py:18-20
+        weight = (hr > 0.01).float() * 9 + 1
+        return (weight * (sr - hr).abs()).mean()
+
+    # ---- train.py:145-159 ----
+    opt_d.zero_grad()
+    with torch.no_grad():
+        fake = generator(lr)
+    real_logits = discriminator(hr)
+    fake_logits = discriminator(fake)
+    d_loss = criterion.discriminator_loss(real_logits, fake_logits)
+    d_loss.backward()
+    assert abs(d_loss.item() - float(gs["d_loss"])) <= 1e-5 * abs(float(gs["d_loss"]))
+    assert max_rel(real_logits.detach().cpu().numpy(), gs["real_logits"]) <= 1e-4
+    assert max_rel(fake_logits.detach().cpu().numpy(), gs["fake_logits"]) <= 2e-4
+    _check_disc_grads_vs_golden({k: p.grad for k, p in discriminator.named_parameters()}, gs)
+    opt_d.step()
+    # ---- train.py:165-176 ----
+    opt_g.zero_grad()
+    fake = generator(lr)
+    fake_logits = discriminator(fake)
+    g_adv = criterion.generator_loss(real_logits.detach(), fake_logits)
+    g_pix = weighted_l1(fake, hr)
+    g_ssim = 1 - TR.ssim(fake, hr)
+    g_loss = 0.005 * g_adv + 1.0 * g_pix + 0.3 * g_ssim
+    g_loss.backward()
+    norm = torch.nn.utils.clip_grad_norm_(generator.parameters(), max_norm=10.0)
+    opt_g.step()
+    # ----
+    for k, v in (("g_adv", g_adv), ("g_pix", g_pix), ("g_ssim", g_ssim), ("g_loss", g_loss)):
+        assert abs(v.item() - float(gs[k])) <= 2e-5 * abs(float(gs[k])), (k, v.item(), float(gs[k]))
+    assert max_rel(fake_logits.detach().cpu().numpy(), gs["fake_logits2"]) <= 2e-4
+    assert abs(norm.item() - float(gs["g_grad_norm"])) <= 1e-3 * float(gs["g_grad_norm"])
+    _check_gen_grads_vs_golden({k: p.grad for k, p in generator.named_parameters()}, gs)
+    with torch.no_grad():
+        assert max_rel(discriminator(hr).cpu().numpy(), gs["real_logits_after"]) <= 1e-4
+    # the next iteration as train.py has it: inside bf16 autocast, discriminator not updated (train.py:160-176)
+    with torch.no_grad():
+        with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+            real_logits = discriminator(hr)
+    opt_g.zero_grad()
+    with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+        fake = generator(lr)
+        fake_logits = discriminator(fake)
+        g_adv = criterion.generator_loss(real_logits.detach(), fake_logits)
+        g_loss = 0.005 * g_adv + 1.0 * weighted_l1(fake, hr) + 0.3 * (1 - TR.ssim(fake, hr))
+    g_loss.backward()
+    torch.nn.utils.clip_grad_norm_(generator.parameters(), max_norm=10.0)
+    opt_g.step()
+    assert fake.dtype == torch.bfloat16 and fake_logits.dtype == torch.bfloat16
+    assert torch.isfinite(g_loss) and all(torch.isfinite(p.grad).all() for p in generator.parameters())
 
 
 def test_adversarial_gradient_at_the_fake_image_vs_reference_golden():

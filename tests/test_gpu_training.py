@@ -157,6 +157,67 @@ def test_conv3x3_wgrad_kernels_vs_torch(wgrad, shape, scale, monkeypatch):
     assert ew <= 2e-5 and eb <= 2e-5
 
 
+@pytest.mark.parametrize("precision,tol", [("fp32", 2e-5), ("f16", 2e-3)])
+def test_conv3x3_wgrad_split_at_64_images_vs_torch_fp64_and_linearity(precision, tol):
+    """BASELINE configs[3] / [4] run 64 images per GPU: the split weight-gradient kernels' slice walk (80 slices with three
+    terms, 168 with one; slices that end inside an image) at that batch against torch's conv2d weight gradient on the CPU in
+    fp64, and against the size-independent property of the op: the gradient of the 64-image batch equals the sum of the
+    gradients of its eight 8-image sub-batches (a different slice walk for the same sums)."""
+    from superresolution_amd import training as T
+    n = 64
+    x = _hash_tensor(71, "wg64.x", (n, 96, 64, 64))
+    gr = _hash_tensor(72, "wg64.g", (n, 96, 64, 64)) * (2.0 ** -12)
+    w = torch.zeros(96, 96, 3, 3, dtype=torch.float64, requires_grad=True)
+    b = torch.zeros(96, dtype=torch.float64, requires_grad=True)
+    for k in range(0, n, 16):                                     # (fp64 CPU conv in four pieces: memory)
+        (F.conv2d(x[k:k + 16].double(), w, b, padding=1) * gr[k:k + 16].double()).sum().backward()
+    ws = T.Workspace(torch.device("cuda"))
+    xc, gc = _nhwc(x).cuda(), _nhwc(gr).cuda()
+    with T.conv_precision(precision):
+        dw, db = T.conv3x3_wgrad(xc, gc, ws)
+        parts = [T.conv3x3_wgrad(xc[k:k + 8].contiguous(), gc[k:k + 8].contiguous(), ws) for k in range(0, n, 8)]
+        dw, db = dw.clone(), db.clone()
+    ew, eb = max_rel(dw.cpu().double().numpy(), w.grad.numpy()), max_rel(db.cpu().double().numpy(), b.grad.numpy())
+    sw = torch.stack([p[0].double() for p in parts]).sum(0)
+    sb = torch.stack([p[1].double() for p in parts]).sum(0)
+    lw, lb = max_rel(dw.cpu().double().numpy(), sw.cpu().numpy()), max_rel(db.cpu().double().numpy(), sb.cpu().numpy())
+    print("wgrad at 64 images", precision, "vs fp64: dw", ew, "db", eb, "| vs the sum of eight sub-batches: dw", lw, "db", lb)
+    assert ew <= tol and eb <= 2e-5
+    # sub-batches see the same dy scale bound only up to their own maximum: fp32 products agree to rounding, f16 products
+    # round the same operands the same way (the scale is a power of two) -- both inside the fp32 bar
+    assert lw <= 2e-5 and lb <= 2e-5
+
+
+def test_pretrain_step_at_64_images_split_vs_winograd_weight_gradients(monkeypatch):
+    """One forward_backward at BASELINE configs[3]'s 64 images per GPU: the default step (split convs, split weight
+    gradient) against the same step with every weight gradient on the exact-fp32 Winograd-domain kernel (SRGEN_WGRAD=wino)
+    -- two independent kernels for 35 of the 39 weight gradients at the batch size the benchmark runs."""
+    from superresolution_amd import Generator, training as T, weights as W
+    lr = torch.from_numpy(W.synthetic_lr_batch(64, 5, "dense")).cuda()
+    hr = torch.from_numpy(W.synthetic_hr_batch(64, seed=6)).cuda()
+    out = {}
+    for mode in ("split", "wino"):
+        monkeypatch.setenv("SRGEN_WGRAD", mode)
+        g = Generator()
+        g.load_state_dict(W.synthetic_state_dict(0))
+        g = g.cuda().train()
+        step = T.PretrainStep(g, lr=1e-4, precision="fp32")
+        step.optimizer.zero_grad()
+        loss = step.forward_backward(lr, hr)
+        out[mode] = (float(loss), {k: p.grad.detach().clone() for k, p in g.named_parameters()})
+        del step, g
+    assert out["split"][0] == out["wino"][0]                     # same forward
+    worst = 0.0
+    for k, a in out["split"][1].items():
+        b = out["wino"][1][k]
+        if _conv_bias_before_bn(k):
+            continue
+        e = max_rel(a.cpu().numpy(), b.cpu().numpy())
+        worst = max(worst, e)
+        assert e <= 1e-4, (k, e)
+    print("64-image step: split vs Winograd weight gradients, worst tensor", worst)
+
+
 def test_pixel_loss_grad_vs_reference_golden(gold, golden):
     from superresolution_amd import pixel_losses, training as T, weights as W
     ws = T.Workspace(torch.device("cuda"))
@@ -233,25 +294,14 @@ def _conv_bias_before_bn(key):
     return key.endswith((".block.0.bias", ".block.3.bias")) or key == "mid.0.bias"
 
 
-def test_pretrain_step_gradients_vs_reference_golden():
-    """One pre-train step of the REAL reference generator (fp32; make_golden_bwd.py step): the loss, the output and the
-    gradient of all 167 parameter tensors (checksums for every tensor, samples for sixteen of them)."""
-    from superresolution_amd import Generator, training as T, weights as W
-    gs = np.load(os.path.join(GOLDEN, "train_step.npz"))
-    g = Generator()
-    g.load_state_dict(W.synthetic_state_dict(0))
-    g = g.cuda().train()
-    step = T.PretrainStep(g, lr=1e-4)
-    lr, hr = _step_batch()
-    loss = step.forward_backward(lr, hr)
-    assert abs(float(loss) - float(gs["loss"])) <= 1e-5 * abs(float(gs["loss"]))
-    names = [k for k, _ in g.named_parameters()]
+def _check_generator_grads_vs_golden(grads, gs, what):
+    """``grads``: {parameter name -> gradient} against train_step.npz (checksums for every tensor, samples for sixteen)."""
+    names = list(grads)
     assert names == [str(k) for k in gs["keys"]]
-    P = dict(g.named_parameters())
     scale_all = float(gs["grad_absmax"].max())
     worst = 0.0
     for i, k in enumerate(names):
-        gr = P[k].grad.detach().double().cpu()
+        gr = grads[k].detach().double().cpu()
         ref_sum, ref_sq = gs["grad_sums"][i]
         if _conv_bias_before_bn(k):
             # true gradient 0 (the BatchNorm behind it removes the mean): both sides hold rounding residue
@@ -268,7 +318,109 @@ def test_pretrain_step_gradients_vs_reference_golden():
             worst = max(worst, e)
             print("  grad sample", k, e)
             assert e <= GRAD_TOL, (k, e)
-    print("pre-train step: worst gradient error vs the reference", worst)
+    print(f"{what}: worst gradient error vs the reference", worst)
+
+
+def test_pretrain_step_gradients_vs_reference_golden():
+    """One pre-train step of the REAL reference generator (fp32; make_golden_bwd.py step): the loss, the output and the
+    gradient of all 167 parameter tensors (checksums for every tensor, samples for sixteen of them)."""
+    from superresolution_amd import Generator, training as T, weights as W
+    gs = np.load(os.path.join(GOLDEN, "train_step.npz"))
+    g = Generator()
+    g.load_state_dict(W.synthetic_state_dict(0))
+    g = g.cuda().train()
+    step = T.PretrainStep(g, lr=1e-4)
+    lr, hr = _step_batch()
+    loss = step.forward_backward(lr, hr)
+    assert abs(float(loss) - float(gs["loss"])) <= 1e-5 * abs(float(gs["loss"]))
+    _check_generator_grads_vs_golden({k: p.grad for k, p in g.named_parameters()}, gs, "pre-train step")
+
+
+# ---- the reference's OWN loop body on the drop-in module (train.py:90-97 with only the import changed) ------------------
+def _ref_weighted_l1(sr, hr):                                     # train.py:18-20, as train.py defines it (plain torch)
+    weight = (hr > 0.01).float() * 9 + 1
+    return (weight * (sr - hr).abs()).mean()
+
+
+def _ref_grad_norm(model):                                        # train.py:23-28
+    total = 0.0
+    for p in model.parameters():
+        if p.grad is not None:
+            total += p.grad.data.norm(2).item() ** 2
+    return total ** 0.5
+
+
+def test_reference_pretrain_loop_body_runs_on_the_dropin_generator():
+    """train.py:90-97 verbatim -- ``optimizer.zero_grad(); sr = generator(lr); loss = weighted_l1(sr, hr) + 0.1 * (1 -
+    ssim(sr, hr)); loss.backward(); grad_norm(generator); optimizer.step()`` -- with a STOCK ``torch.optim.AdamW`` on
+    ``superresolution_amd.Generator``: ``loss.backward()`` reaches the HIP backward pass through autograd.GeneratorTrainFn.
+    Without autocast the step is the reference's fp32 step: loss, every p.grad and the running statistics against
+    train_step.npz / generator_train.npz; the AdamW update against torch's own on the same gradients (it IS torch's).
+    ``ssim`` is the stock-torch restatement of utils.py:21-41 (oracle/torch_ref.py), differentiated by torch."""
+    from oracle import torch_ref as TR
+    from superresolution_amd import Generator, weights as W
+    gs = np.load(os.path.join(GOLDEN, "train_step.npz"))
+    gt = np.load(os.path.join(GOLDEN, "generator_train.npz"))
+    generator = Generator()
+    generator.load_state_dict(W.synthetic_state_dict(0))
+    generator = generator.cuda()
+    optimizer = torch.optim.AdamW(generator.parameters(), lr=1e-4)            # train.py:270
+    generator.train()                                                          # train.py:80
+    lr, hr = _step_batch()
+    before = [p.detach().clone() for p in generator.parameters()]
+    # ---- train.py:90-97 (autocast left out: the fp32 fixture) ----
+    optimizer.zero_grad()
+    sr = generator(lr)
+    loss = _ref_weighted_l1(sr, hr) + 0.1 * (1 - TR.ssim(sr, hr))
+    loss.backward()
+    g = _ref_grad_norm(generator)
+    optimizer.step()
+    # ----
+    assert sr.dtype == torch.float32 and sr.grad_fn is not None
+    assert abs(loss.item() - float(gs["loss"])) <= 1e-5 * abs(float(gs["loss"]))
+    grads = {k: p.grad for k, p in generator.named_parameters()}
+    assert all(v is not None for v in grads.values())
+    _check_generator_grads_vs_golden(grads, gs, "reference loop body on the drop-in")
+    flat_sq = sum(float(gs["grad_sums"][i][1]) for i in range(len(gs["keys"])))
+    assert abs(g - flat_sq ** 0.5) <= 1e-3 * flat_sq ** 0.5
+    assert any(not torch.equal(a, p.detach()) for a, p in zip(before, generator.parameters()))
+    sd = generator.state_dict()
+    keys = [str(k) for k in gt["bn_keys"]]
+    em = max(np.abs(sd[k + ".running_mean"].cpu().numpy() - gt["mean1"][i]).max() for i, k in enumerate(keys))
+    assert em <= 1e-5 and int(sd[keys[0] + ".num_batches_tracked"]) == 1001
+    with pytest.raises(RuntimeError, match="second time"):
+        loss.backward()
+    # a second iteration, now exactly as train.py:90-94 has it (inside bf16 autocast; zero_grad sets p.grad to None)
+    optimizer.zero_grad()
+    assert all(p.grad is None for p in generator.parameters())
+    with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+        sr = generator(lr)
+        loss2 = _ref_weighted_l1(sr, hr) + 0.1 * (1 - TR.ssim(sr, hr))
+    loss2.backward()
+    optimizer.step()
+    assert sr.dtype == torch.bfloat16
+    assert loss2.item() < loss.item()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in generator.parameters())
+    # the eval forward picks the stepped weights up
+    with torch.no_grad():
+        y = generator.eval()(lr)
+    assert torch.isfinite(y).all()
+
+
+def test_pixel_loss_function_is_differentiable_and_matches_the_torch_expression():
+    """superresolution_amd.pixel_loss (autograd.PixelLossFn): value and gradient of w1 * weighted_l1 + w2 * (1 - ssim)
+    against the torch expression of train.py:18-20,93 differentiated by torch."""
+    from oracle import torch_ref as TR
+    from superresolution_amd import pixel_loss, weights as W
+    sr0 = torch.from_numpy(W.synthetic_hr_batch(3, seed=5)).cuda()
+    hr = torch.from_numpy(W.synthetic_hr_batch(3, seed=1)).cuda()
+    a, b = sr0.clone().requires_grad_(), sr0.clone().requires_grad_()
+    la = 2.0 * pixel_loss(a, hr, 1.0, 0.3)
+    lb = 2.0 * (_ref_weighted_l1(b, hr) + 0.3 * (1 - TR.ssim(b, hr)))
+    la.backward()
+    lb.backward()
+    assert abs(la.item() - lb.item()) <= 1e-5 * abs(lb.item())
+    assert max_rel(a.grad.cpu().numpy(), b.grad.cpu().numpy()) <= TOL
 
 
 def test_pretrain_step_updates_parameters_and_running_stats():

@@ -87,8 +87,10 @@ def test_state_dict_surface_matches_reference_contract():
 def test_forward_fails_loudly_off_gpu_and_in_train_mode():
     g = Generator()
     x = torch.zeros(1, 3, 64, 64)
-    with pytest.raises(NotImplementedError):
-        g.train()(x)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        g.train()(x)                                     # train mode has no eager fallback either
+    with pytest.raises(NotImplementedError, match="input image"):
+        g.train()(x.clone().requires_grad_())
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         g.eval()(x)
     with pytest.raises(RuntimeError, match="channels"):
