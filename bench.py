@@ -18,9 +18,13 @@ Workloads (BASELINE.json `configs`), both measured by every run and printed by r
         8 GPUs), runs them through superresolution_amd.evaluate.validate -- generator forward, the PSNR/SSIM/L1
         kernel per batch, sums kept on the device -- and ONE RCCL SUM all-reduce of {sum psnr, sum ssim, sum l1,
         batches} ends it (train.py:57-72 semantics).  `--workload cfg2` makes this leg the headline instead.
-  cfg3 / cfg4  (only with `--workload cfg3|cfg4`, a line of their own)  configs[3] / [4]: the pre-train step and the
-        GAN iteration at 64 images per GPU, fp32, data parallel: every rank steps on its own batch and one all-reduce
-        per optimizer step averages the flat gradient buffer (superresolution_amd/training.py, gan_training.py).
+  cfg3 / cfg4  (objects `cfg3` / `cfg4` of the default line, each with an "fp32" and an "f16" entry = the two conv
+        arithmetics, <= 10 steps; `--workload cfg3|cfg4 [--train-precision f16]`: a line of their own)  configs[3] / [4]:
+        the pre-train step and the GAN iteration at 64 images per GPU, fp32 tensors, data parallel: every rank steps on
+        its own batch and one all-reduce per optimizer step averages the flat gradient buffer
+        (superresolution_amd/training.py, gan_training.py).  Each carries `time_by_operator_class` (one single-stream
+        step with a HIP event pair around every operator call), a `roofline` for the class with the largest share, and a
+        `cpu_baseline`: the same step with stock torch CPU ops + autograd (oracle/torch_ref.py) at batch 4.
 
 Further objects on the line:
   roofline      dominant kernel = the 33 trunk 3x3 convs (75 % of the FLOPs).  `achieved` = FLOPs the matrix
@@ -136,29 +140,70 @@ def spawn_ranks(n, argv):
     raise SystemExit(bad[0] if bad else 0)
 
 
-def training_leg(args, dev, rank, n_ranks, use_dist):
-    """BASELINE.json configs[3] (pre-train step) / configs[4] (GAN iteration): 64 images per GPU, fp32, data parallel --
-    every rank steps on its own batch and ONE all-reduce per optimizer averages the flat gradient buffer (RCCL)."""
+def cpu_training_baseline(workload, batch=4, threads=None):
+    """One optimizer step (cfg3) / one GAN iteration with a discriminator update (cfg4) of the reference's training loop
+    restated with stock torch CPU ops and torch autograd (oracle/torch_ref.py; fp32), on the box's host cores."""
+    import torch
+    from oracle import torch_ref
+    from superresolution_amd import Discriminator, weights as W
+    threads = threads or min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    sd = W.synthetic_state_dict(0)
+    P = {k: v.clone().requires_grad_() for k, v in sd.items() if v.is_floating_point() and "running" not in k}
+    opt = torch.optim.AdamW(list(P.values()), lr=1e-4)
+    lr = torch.from_numpy(W.synthetic_lr_batch(batch, 2, "dense"))
+    hr = torch.from_numpy(W.synthetic_hr_batch(batch, seed=1))
+    if workload == "cfg3":
+        run = lambda: torch_ref.pretrain_step(P, opt, lr, hr)
+        what = "pre-train steps (train.py:90-97)"
+    else:
+        torch.manual_seed(3)
+        D = {k: v.detach().clone().requires_grad_() for k, v in Discriminator().named_parameters()}
+        opt_d = torch.optim.AdamW(list(D.values()), lr=1e-6)
+        it = [0]
+
+        def run():
+            it[0] += 1
+            return torch_ref.gan_iteration(P, D, opt, opt_d, lr, hr, update_d=(it[0] - 1) % 3 == 0)
+        what = "GAN iterations, discriminator updated every 3rd (train.py:145-176, config.py:21)"
+    run()
+    iters = 3
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        run()
+    dt = time.perf_counter() - t0
+    return {"value": round(batch * iters / dt, 3), "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"{iters} fp32 {what} at batch {batch} through oracle/torch_ref.py (stock torch CPU ops + autograd), {dt:.1f} s"}
+
+
+def training_object(workload, precision, dev, rank, n_ranks, use_dist, n=64, steps=10, warmup=3, reuse_forward=False,
+                    cpu=None):
+    """BASELINE.json configs[3] (pre-train step) / configs[4] (GAN iteration): `n` images per GPU, data parallel -- every
+    rank steps on its own batch and ONE all-reduce per optimizer averages the flat gradient buffer (RCCL).  Returns the
+    object bench.py prints (a line of its own with --workload cfg3|cfg4, objects `cfg3` / `cfg4` of the default line).
+    Its `roofline` is that of the operator class with the largest share of one step's device time, measured live: every
+    operator call of one single-stream step bracketed by HIP events (training.profile_ops)."""
     import torch
     import torch.distributed as dist
     from superresolution_amd import Discriminator, Generator, training as T, weights as W
     from superresolution_amd.gan_training import GanStep
-    n = args.train_batch
     g = Generator()
     g.load_state_dict(W.synthetic_state_dict(0))
     g = g.to(dev).train()
     gen = torch.Generator(device="cpu").manual_seed(4321 + rank)
     lr = torch.rand((n, 3, 64, 64), generator=gen).to(dev)
     hr = torch.rand((n, 3, 125, 125), generator=gen).to(dev)
-    if args.workload == "cfg3":
-        step = T.PretrainStep(g, lr=1e-4, precision=args.train_precision)
+    if workload == "cfg3":
+        step = T.PretrainStep(g, lr=1e-4, precision=precision)
+        owner = step
         run = lambda: step.step(lr, hr)
         name = f"BASELINE.json configs[3]: pre-train step (forward, loss, backward, AdamW), {n} images per GPU, fp32 tensors"
         metric = "pre-train step images/s"
     else:
         torch.manual_seed(3)
         d = Discriminator().to(dev).train()
-        gan = GanStep(g, d, precision=args.train_precision, reuse_forward=args.gan_reuse_forward)
+        gan = GanStep(g, d, precision=precision, reuse_forward=reuse_forward)
+        owner = gan.gen
         it = [0]
 
         def run():
@@ -166,7 +211,7 @@ def training_leg(args, dev, rank, n_ranks, use_dist):
             return gan.step(lr, hr, update_d=(it[0] - 1) % 3 == 0)["g_loss"]      # config.py:21 discriminator_update_freq = 3
         name = (f"BASELINE.json configs[4]: GAN iteration (discriminator half-step every 3rd iteration + generator "
                 f"half-step), {n} images per GPU, fp32 tensors"
-                + (", generator forward of the discriminator half-step reused by the generator half-step" if args.gan_reuse_forward else ""))
+                + (", generator forward of the discriminator half-step reused by the generator half-step" if reuse_forward else ""))
         metric = "GAN iteration images/s"
 
     def barrier():
@@ -174,11 +219,11 @@ def training_leg(args, dev, rank, n_ranks, use_dist):
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(max(args.warmup, 3)):
+    for _ in range(max(warmup, 3)):
         run()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         loss = run()
     barrier()
     dt = time.perf_counter() - t0
@@ -186,64 +231,55 @@ def training_leg(args, dev, rank, n_ranks, use_dist):
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    # dominant kernel: the 3x3 weight gradient (43.5 GFLOP algorithmic per launch at 64 images; the split kernel executes
-    # 3 f16 MFMAs per product, the Winograd-domain kernel 16/36 on the fp32 MFMA), timed alone with HIP events; the
-    # gradient operand carries its partial maxima as in the step (no absmax pass inside the timed op)
-    ws = T.Workspace(dev)
-    xa = torch.randn((n, 64, 64, 96), device=dev)
-    if T.wgrad_path() == "split":
-        xa.amax_slots = T.absmax(xa)
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(21)]
-    with T.conv_precision(args.train_precision):
-        for _ in range(3):
-            T.conv3x3_wgrad(xa, xa, ws)
-        ev[0].record()
-        for i in range(20):
-            T.conv3x3_wgrad(xa, xa, ws)
-            ev[i + 1].record()
-        ev[-1].synchronize()
-    wg_ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(20))[10]
-    flop_alg = 2.0 * n * 4096 * 96 * 864
-    wpath = T.wgrad_path()
-    f16 = args.train_precision == "f16"
-    ratio, peak, kname = ((1.0 if f16 else SPLIT_EXECUTED, PEAK["f16"], f"wg1::conv3x3_wgrad_split_kernel<{1 if f16 else 3}> + conv3x3_wgrad_reduce_kernel") if wpath == "split"
-                          else (WINO_EXECUTED, PEAK["f32"], "conv3x3_wgrad_wino_lds_kernel + sum + final") if wpath == "wino"
-                          else (1.0, PEAK["f32"], "conv3x3_wgrad_kernel + reduce"))
-    flop = flop_alg * ratio
-    # HBM bytes per weight-gradient launch from the committed PMC passes of this step (tools/prof_train.sh ->
-    # profiles/r02w_pretrain_pmc.json: FETCH_SIZE x 2, the gfx950 correction for 16 B/lane reads, + WRITE_SIZE, in KB)
-    traffic = None
+    # where the step's device time goes: three steps (one discriminator update among them for cfg4) on ONE stream, every
+    # operator call between two HIP events
+    side, owner.side = owner.side, None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02w_pretrain_pmc.json")))["f16" if f16 else "fp32"]
-        c = next(v for k, v in pmc.items() if "conv3x3_wgrad_split_kernel" in k) if wpath == "split" else None
-        if c and n == 64:
-            traffic = int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)
-    except (OSError, KeyError, StopIteration, ValueError):
-        pass
-    if rank == 0:
-        print(json.dumps({
-            "metric": metric, "value": round(n * n_ranks * args.steps / dt, 1), "unit": "images/s", "n_gpus": n_ranks,
-            "steps": args.steps, "warmup": max(args.warmup, 3), "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16 products, f32 accumulation and tensors" if f16 else "f32", "data": "synthetic",
-            "config": {"workload": name, "batch_per_gpu": n, "global_batch": n * n_ranks, "parallelism": f"dp{n_ranks}",
-                       "conv_products": ("f16: the generator's 3x3 convs (forward, data and weight gradient) multiply operands "
-                                         "rounded to f16 after power-of-two range scaling, one MFMA per product -- the reference "
-                                         "runs this step under bf16 autocast (train.py:91); tests/test_gpu_training.py shows the "
-                                         "gradients closer to the reference's fp32 step than its own autocast step is") if f16
-                                        else "fp32 accuracy (three f16 MFMAs per product)",
-                       "precision": f"fp32 tensors and accumulation; 3x3 conv products: {T.conv_path()} (forward, data "
-                                    f"gradient), {wpath} (weight gradient) -- split = two-term f16 splits of both "
-                                    "operands, three f16 MFMAs per product, operands range-scaled by powers of two",
-                       "collective": "one all-reduce of the flat gradient buffer per optimizer step (12.86 MB generator, "
-                                     "23.5 MB discriminator)"},
-            "loss_last": float(loss),
-            "roofline": {"bound": "mfma", "kernel": kname + " (38 launches per generator backward)",
-                         "achieved": round(flop / (wg_ms * 1e-3) / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(flop / (wg_ms * 1e-3) / 1e12 / peak, 4), "traffic": traffic,
-                         "ms_per_launch": round(wg_ms, 4), "flop_per_launch_executed": flop, "flop_per_launch_algorithmic": flop_alg,
-                         "algorithmic_tflops": round(flop_alg / (wg_ms * 1e-3) / 1e12, 2)},
-            "cpu_baseline": None}), flush=True)
+        with T.profile_ops() as prof:
+            for _ in range(3):
+                run()
+    finally:
+        owner.side = side
+    total = sum(v[0] for v in prof.values()) or 1.0
+    classes = {k: {"ms_per_step": round(v[0] / 3, 3), "launches_per_step": round(v[1] / 3, 1), "share": round(v[0] / total, 3)}
+               for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
+    top, (top_ms, top_calls, top_work) = max(prof.items(), key=lambda kv: kv[1][0])
+    f16 = precision == "f16"
+    wpath = T.wgrad_path()
+    if top.startswith("conv3x3"):
+        split = (T.conv_path() if "forward" in top else wpath) == "split"
+        ratio, peak = ((1.0 if f16 else SPLIT_EXECUTED), PEAK["f16"]) if split else (WINO_EXECUTED, PEAK["f32"])
+        kname = ("c3s::conv3x3_f32s_kernel<*, TERMS=%d>" % (1 if f16 else 3) if "forward" in top
+                 else "wg1::conv3x3_wgrad_split_kernel<%d> + conv3x3_wgrad_reduce_kernel" % (1 if f16 else 3)) if split else top
+        ach = top_work * ratio / (top_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": f"{kname} ({top}: {round(top_calls / 3)} launches per step, the class with the "
+                                           f"largest share of the step's device time: {classes[top]['share']:.0%})",
+                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                "ms_per_launch": round(top_ms / top_calls, 4), "flop_per_launch_executed": top_work * ratio / top_calls,
+                "flop_per_launch_algorithmic": top_work / top_calls,
+                "algorithmic_tflops": round(top_work / (top_ms * 1e-3) / 1e12, 2)}
+    else:
+        ach = top_work / (top_ms * 1e-3) / 1e9 if top_work else None
+        roof = {"bound": "hbm" if top_work else "mfma", "kernel": f"{top} ({round(top_calls / 3)} calls per step, largest share: "
+                                                                  f"{classes[top]['share']:.0%})",
+                "achieved": round(ach, 1) if ach else None, "peak": 8000.0, "unit": "GB/s",
+                "frac": round(ach / 8000.0, 4) if ach else None, "traffic": None, "ms_per_launch": round(top_ms / top_calls, 4)}
+    return {
+        "metric": metric, "value": round(n * n_ranks * steps / dt, 1), "unit": "images/s", "n_gpus": n_ranks,
+        "steps": steps, "warmup": max(warmup, 3), "ms_per_step": round(dt / steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f16 products, f32 accumulation and tensors" if f16 else "f32", "data": "synthetic",
+        "config": {"workload": name, "batch_per_gpu": n, "global_batch": n * n_ranks, "parallelism": f"dp{n_ranks}",
+                   "conv_products": ("f16: the generator's 3x3 convs (forward, data and weight gradient) multiply operands "
+                                     "rounded to f16 after power-of-two range scaling, ONE f16 MFMA per product -- the reference "
+                                     "runs this step under bf16 autocast (train.py:91); tests/test_gpu_training.py shows the "
+                                     "gradients closer to the reference's fp32 step than its own autocast step is") if f16
+                                    else "fp32 accuracy: two-term f16 splits of both operands, THREE f16 MFMAs per product",
+                   "precision": f"fp32 tensors and accumulation; 3x3 conv kernels: {T.conv_path()} (forward, data gradient), "
+                                f"{wpath} (weight gradient); operands range-scaled by powers of two",
+                   "collective": "one all-reduce of the flat gradient buffer per optimizer step (12.86 MB generator, "
+                                 "23.5 MB discriminator)"},
+        "loss_last": float(loss), "roofline": roof, "time_by_operator_class": classes, "cpu_baseline": cpu}
 
 
 def main():
@@ -265,6 +301,7 @@ def main():
     ap.add_argument("--cfg2-reps", type=int, default=5)
     ap.add_argument("--median-steps", type=int, default=50, help="HIP-event-timed steps of the median leg (>= 50)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-training-legs", action="store_true", help="default line without the cfg3 / cfg4 objects")
     ap.add_argument("--lean", action="store_true", help="profiling runs (rocprofv3): only the K timed steps of --dtype and "
                     "the per-kernel HIP-event leg; the line then carries no bf16 / cfg2 / psnr / hbm objects")
     ap.add_argument("--dry-run", action="store_true", help="ranks report their rendezvous environment and exit "
@@ -288,8 +325,11 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a number for the wrong rank count")
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline()                          # host-only leg first: the GPU legs then run back to back
+    cpu_train = {}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload in ("cfg1", "cfg2"):
+        cpu = cpu_baseline()                          # host-only legs first: the GPU legs then run back to back
+        if not args.lean and not args.no_training_legs:
+            cpu_train = {w: cpu_training_baseline(w) for w in ("cfg3", "cfg4")}
 
     import numpy as np
     import torch
@@ -311,7 +351,13 @@ def main():
     n_ranks = dist.get_world_size() if use_dist else 1
 
     if args.workload in ("cfg3", "cfg4"):
-        training_leg(args, dev, rank, n_ranks, use_dist)
+        cpu_t = None
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            cpu_t = cpu_training_baseline(args.workload)
+        obj = training_object(args.workload, args.train_precision, dev, rank, n_ranks, use_dist, n=args.train_batch,
+                              steps=args.steps, warmup=args.warmup, reuse_forward=args.gan_reuse_forward, cpu=cpu_t)
+        if rank == 0:
+            print(json.dumps(obj), flush=True)
         if use_dist:
             dist.destroy_process_group()
         return
@@ -367,7 +413,7 @@ def main():
                 e.synchronize()                       # keep the launch queue short: honest per-step intervals
         evs[-1].synchronize()
         ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(done))
-        return {"steps": done, "median_ms_per_step": round(ms[done // 2], 4), "min_ms_per_step": round(ms[0], 4),
+        return {"median_steps": done, "median_ms_per_step": round(ms[done // 2], 4), "min_ms_per_step": round(ms[0], 4),
                 "p90_ms_per_step": round(ms[int(done * 0.9)], 4)}
 
     def kernel_profile(dt_name, reps=3):
@@ -503,6 +549,18 @@ def main():
     steps_other = max(20, args.steps // 2)
     med_other = median_forward(other, 50)
     c2 = cfg2_leg(args.cfg2_reps)
+    # configs[3] / [4] on the same line: both conv arithmetics, a few steps each (their own lines: --workload cfg3|cfg4)
+    train_objs = {}
+    if not args.no_training_legs:
+        for wl in ("cfg3", "cfg4"):
+            train_objs[wl] = {}
+            for prec in ("fp32", "f16"):
+                o = training_object(wl, prec, dev, rank, n_ranks, use_dist, n=args.train_batch,
+                                    steps=max(3, min(10, args.steps)), warmup=3, cpu=cpu_train.get(wl))
+                for k in ("higher_is_better", "scaling", "vs_baseline", "data", "n_gpus", "unit"):
+                    o.pop(k, None)
+                train_objs[wl][prec] = o
+            torch.cuda.empty_cache()
 
     out = None
     if rank == 0:
@@ -570,6 +628,7 @@ def main():
         }
         if exact_obj is not None:
             out["f32_exact_mfma"] = exact_obj
+        out.update(train_objs)
         out["config"]["precision"] = {
             "f32": ("fp32 tensors in HBM, fp32 accumulation; 3x3 conv products via two-term f16 splits of both operands "
                     "(3 f16 MFMAs per product, error of an fp32 product: see psnr.max_rel_err_f32 beside "

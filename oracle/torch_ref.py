@@ -88,3 +88,88 @@ def ssim(sr, hr, window_size=11, sigma=1.5):
     num = (2 * mx * my + 0.01 ** 2) * (2 * sxy + 0.03 ** 2)
     den = (mx * mx + my * my + 0.01 ** 2) * (sxx + syy + 0.03 ** 2)
     return (num / den.clamp(min=1e-8)).mean()
+
+
+# ---- training steps on the CPU with torch autograd: bench.py's cpu_baseline for BASELINE configs[3] / [4] ----------------
+def generator_forward_train(P: Dict[str, torch.Tensor], x: torch.Tensor, num_blocks: int = 16) -> torch.Tensor:
+    """Generator.py:74-80 in TRAIN mode (batch-statistics BatchNorm, no running-statistics update) on a dict of
+    parameters that may require grad -- the graph train.py:92 builds."""
+    def bn(t, p):
+        return F.batch_norm(t, None, None, P[p + ".weight"], P[p + ".bias"], training=True, eps=1e-5)
+
+    x1 = F.prelu(F.conv2d(x, P["input.0.weight"], P["input.0.bias"], padding=4), P["input.1.weight"])
+    cur, idx = x1, 0
+    for i in range(num_blocks):
+        p = f"blocks.{idx}.block"
+        t = F.prelu(bn(F.conv2d(cur, P[p + ".0.weight"], P[p + ".0.bias"], padding=1), p + ".1"), P[p + ".2.weight"])
+        t = bn(F.conv2d(t, P[p + ".3.weight"], P[p + ".3.bias"], padding=1), p + ".4")
+        cur = cur + 0.1 * t
+        idx += 1
+        if i in (7, 15):
+            p = f"blocks.{idx}.fc"
+            sc = torch.sigmoid(F.conv2d(F.relu(F.conv2d(F.adaptive_avg_pool2d(cur, 1), P[p + ".0.weight"], P[p + ".0.bias"])),
+                                        P[p + ".2.weight"], P[p + ".2.bias"]))
+            cur = cur * sc
+            idx += 1
+    s = x1 + bn(F.conv2d(cur, P["mid.0.weight"], P["mid.0.bias"], padding=1), "mid.1")
+    u = F.prelu(F.pixel_shuffle(F.conv2d(s, P["upsample.conv.weight"], P["upsample.conv.bias"], padding=1), 2),
+                P["upsample.act.weight"])
+    o = F.prelu(F.conv2d(u, P["output.0.weight"], P["output.0.bias"], padding=1), P["output.1.weight"])
+    return F.conv2d(o, P["output.2.weight"], P["output.2.bias"], padding=4)[:, :, :125, :125]
+
+
+def discriminator_forward(D: Dict[str, torch.Tensor], x: torch.Tensor) -> torch.Tensor:
+    """Discriminator.py:22-38,49-50 on a dict of its 20 parameters."""
+    keys = ["backbone.0"] + [f"backbone.{k}.block.0" for k in range(2, 9)] + ["head.0", "head.2"]
+    strides = [1, 2, 1, 2, 1, 2, 1, 2, 1, 1]
+    h = x
+    for i, (k, st) in enumerate(zip(keys, strides)):
+        h = F.conv2d(h, D[k + ".weight"], D[k + ".bias"], stride=st, padding=1)
+        if i < 9:
+            h = F.leaky_relu(h, 0.2)
+    return h
+
+
+def weighted_l1(sr, hr):
+    """train.py:18-20."""
+    return (((hr > 0.01).float() * 9 + 1) * (sr - hr).abs()).mean()
+
+
+def _ragan(real, fake, t_real, t_fake):
+    """Discriminator.py:53-72."""
+    bce = F.binary_cross_entropy_with_logits
+    rf, fr = real - fake.mean(), fake - real.mean()
+    return (bce(rf, torch.full_like(rf, t_real)) + bce(fr, torch.full_like(fr, t_fake))) / 2
+
+
+def pretrain_step(P, opt, lr, hr):
+    """train.py:90-97 (fp32): one optimizer step; returns the loss."""
+    opt.zero_grad()
+    sr = generator_forward_train(P, lr)
+    loss = weighted_l1(sr, hr) + 0.1 * (1 - ssim(sr, hr))
+    loss.backward()
+    opt.step()
+    return float(loss.detach())
+
+
+def gan_iteration(P, D, opt_g, opt_d, lr, hr, update_d=True):
+    """train.py:145-176 (fp32): one iteration; returns g_loss."""
+    if update_d:
+        opt_d.zero_grad()
+        with torch.no_grad():
+            fake = generator_forward_train(P, lr)
+        real_logits = discriminator_forward(D, hr)
+        d_loss = _ragan(real_logits, discriminator_forward(D, fake), 0.9, 0.1)
+        d_loss.backward()
+        opt_d.step()
+    else:
+        with torch.no_grad():
+            real_logits = discriminator_forward(D, hr)
+    opt_g.zero_grad()
+    fake = generator_forward_train(P, lr)
+    g_loss = (0.005 * _ragan(real_logits.detach(), discriminator_forward(D, fake), 0.0, 1.0) + weighted_l1(fake, hr)
+              + 0.3 * (1 - ssim(fake, hr)))
+    g_loss.backward()
+    torch.nn.utils.clip_grad_norm_(list(P.values()), 10.0)
+    opt_g.step()
+    return float(g_loss.detach())

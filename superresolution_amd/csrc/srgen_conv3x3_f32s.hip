@@ -166,15 +166,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32s_kernel(Conv3x3Args a, int
 #pragma unroll
         for (int it = 0; it < A_REGS; ++it) stage[it] = *(const f32x4*)(in + aoff[it]);
     };
+    // split of one 16-byte piece: hi = f16(v * 2^kx), lo = f16(v * 2^kx - hi), two instructions per element
+    // (v_fma_mixlo/hi_f16: fp32 x fp32 + f16 -> f16, each writing one half of the packed destination: no separate scaling,
+    // conversion back to fp32, subtraction or packing); a piece outside the image is multiplied by 0 instead of selected
     auto convert_a = [&](int it) {
-        const bool ok = (aok >> it) & 1u;
-        const float in_mul = pow2f(kx_stage);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float v = ok ? stage[it][e] * in_mul : 0.f;
-            chi[it][e] = (_Float16)v;
-            if (TERMS == 3) clo[it][e] = (_Float16)(v - (float)chi[it][e]);
+        const float m = ((aok >> it) & 1u) ? pow2f(kx_stage) : 0.f;
+        unsigned h01, h23, l01 = 0, l23 = 0;      // (mixlo leaves the destination's high half for mixhi to fill: "=&v", then "+v")
+        const f32x4 v = stage[it];
+        asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=&v"(h01) : "v"(v.x), "v"(m));
+        asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h01) : "v"(v.y), "v"(m));
+        asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=&v"(h23) : "v"(v.z), "v"(m));
+        asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h23) : "v"(v.w), "v"(m));
+        if (TERMS == 3) {
+            asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=&v"(l01) : "v"(v.x), "v"(m), "v"(h01));
+            asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l01) : "v"(v.y), "v"(m), "v"(h01));
+            asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=&v"(l23) : "v"(v.z), "v"(m), "v"(h23));
+            asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l23) : "v"(v.w), "v"(m), "v"(h23));
         }
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        chi[it] = __builtin_bit_cast(h4, (u32x2){h01, h23});
+        if (TERMS == 3) clo[it] = __builtin_bit_cast(h4, (u32x2){l01, l23});
     };
     auto store_a = [&]() {
 #pragma unroll
@@ -230,6 +241,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32s_kernel(Conv3x3Args a, int
     plan_a(cur);
     load_a(cur, 0);
     issue_w(cur.cb, 0, 0);
+    issue_w(cur.cb, 1, 1);                            // (an item's group 1 is requested before the item starts: see the epilogue)
     for (int i = tid; i < CB * 96; i += 256) {
         ldsBias[i] = a.bias[i];
         ldsSlope[i] = act ? a.slope[i] : 1.f;
@@ -292,7 +304,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32s_kernel(Conv3x3Args a, int
                 // in the previous group, every wave is past the barrier that ended it); in a chunk's first group the
                 // next chunk's pixels are fetched, in its last they are split into (hi, lo) between the MFMAs
                 if (!(ABL & 16)) {
-                    if (g + 1 < 18) issue_w(cur.cb, g + 1, slot ^ 1);
+                    // (group 1's weights were requested in front of the previous item's stores, or in the prologue)
+                    if (g == 0) { }
+                    else if (g + 1 < 18) issue_w(cur.cb, g + 1, slot ^ 1);
                     else issue_w(nx.cb, 0, slot ^ 1);
                     if (ky == 0) {
                         if (c + 1 < NCH) load_a(cur, c + 1);
@@ -322,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32s_kernel(Conv3x3Args a, int
 #pragma unroll
                     for (int i = 0; i < NMF; ++i) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, TERMS == 3 ? 3 : 4, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, TERMS == 3 ? 1 : 3, 0);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -338,7 +352,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32s_kernel(Conv3x3Args a, int
 #pragma unroll
                     for (int i = 0; i < NMF; ++i) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, TERMS == 3 ? 4 : 6, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, TERMS == 3 ? 2 : 5, 0);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -352,7 +366,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32s_kernel(Conv3x3Args a, int
 #pragma unroll
                     for (int i = 0; i < NMF; ++i) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, TERMS == 3 ? 3 : 4, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, TERMS == 3 ? 1 : 3, 0);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -363,7 +377,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32s_kernel(Conv3x3Args a, int
                 // this wave's weight copies (and pixel stores) have landed.  In a chunk's first group the seven pixel
                 // loads issued after the copies may stay in flight (loads return in order): they are first needed in
                 // the chunk's last group, and an HBM miss takes about as long as one group
-                if (ky == 0 && !(ABL & 1024)) __builtin_amdgcn_s_waitcnt(0x0077);      // vmcnt(7) lgkmcnt(0)
+                // An item's first group needs group 1's weights next, and those were requested BEFORE the previous item's
+                // epilogue: the 24 output stores of that epilogue and this group's seven pixel loads, all younger, may
+                // stay in flight (gfx950 retires vector loads and stores through ONE in-order counter: waiting for anything
+                // younger than the stores would wait out every store acknowledgement of the burst all workgroups emit at
+                // once).  Group 1 ends with vmcnt(0): the stores get two groups of MFMAs as cover instead of one.
+                if (g == 0 && !(ABL & 1024)) __builtin_amdgcn_s_waitcnt((ABL & 8192) ? 0x0077 : 0x407F);   // vmcnt(31) lgkmcnt(0)
+                else if (ky == 0 && !(ABL & 1024)) __builtin_amdgcn_s_waitcnt(0x0077);      // vmcnt(7) lgkmcnt(0)
                 else wait_all();
                 if (!(ABL & 64)) barrier();
                 if (ky == 2 && !(ABL & 4096)) __builtin_amdgcn_s_setprio(0);
@@ -379,6 +399,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32s_kernel(Conv3x3Args a, int
         else
             out += (((size_t)cur.n * HW + y) * HW + x0 + p) * kC + 4 * h;
         float psum[3][16];
+        // the next item's group 1 into slot 1 (group 17, its last reader, ended with a barrier), requested in front of the stores
+        if (has_next && !(ABL & 16)) issue_w(nx.cb, 1, 1);
         if (RES) {
 #pragma unroll
             for (int k = 1; k < 6; ++k) load_res(cur, k);

@@ -22,7 +22,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from . import _lib
-from .training import FlatAdamW, PretrainStep, Workspace, allreduce_mean, conv_precision, packed_weights, pixel_loss_grad, resolve_precision
+from .training import FlatAdamW, PretrainStep, Workspace, _timed, allreduce_mean, conv_precision, packed_weights, pixel_loss_grad, resolve_precision
 
 SLOPE = 0.2                                  # nn.LeakyReLU(0.2), Discriminator.py:10,24,36
 
@@ -95,6 +95,7 @@ class DiscriminatorGrad:
         return out
 
     # -- forward --------------------------------------------------------------------------------------------------------
+    @_timed("discriminator forward")
     def forward(self, x: torch.Tensor):
         if not x.is_cuda or x.dim() != 4 or x.shape[1] != 3:
             raise RuntimeError(f"expected an (n, 3, h, w) ROCm tensor, got {tuple(x.shape)} on {x.device}; there is no CPU fallback")
@@ -135,6 +136,7 @@ class DiscriminatorGrad:
                 p.grad = torch.zeros_like(p)
         return conv.weight.grad, conv.bias.grad
 
+    @_timed("discriminator backward")
     def backward(self, dlogits: torch.Tensor, saved: dict, want_wgrad: bool = True, want_dimg: bool = False,
                  into: Optional[Dict[str, torch.Tensor]] = None) -> Optional[torch.Tensor]:
         """``into``: {state_dict key -> contiguous fp32 tensor} the weight / bias gradients are WRITTEN to (the autograd

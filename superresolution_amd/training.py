@@ -30,6 +30,58 @@ def _stream(t: torch.Tensor) -> int:
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
+# ---- per-operator-class timing (bench.py: which kernel class a training step spends its time in) -----------------------
+# Inside ``profile_ops()`` every operator call below is bracketed by a HIP event pair on the stream it launches on; the
+# block yields {class: [ms, calls, work]} (work = executed-independent algorithmic FLOPs for the MFMA-bound classes, bytes
+# moved for the HBM-bound ones), filled when the block ends.  Use with ONE stream (PretrainStep(...).side = None): on two
+# streams the classes overlap and their times do not add up to the step.
+_PROFILE = [None]
+
+
+@contextlib.contextmanager
+def profile_ops():
+    rec, out = [], {}
+    old = _PROFILE[0]
+    _PROFILE[0] = rec
+    try:
+        yield out
+    finally:
+        _PROFILE[0] = old
+        torch.cuda.synchronize()
+        for cls, e0, e1, work in rec:
+            a = out.setdefault(cls, [0.0, 0, 0.0])
+            a[0] += e0.elapsed_time(e1)
+            a[1] += 1
+            a[2] += work
+
+
+def _timed(cls: str, work=lambda *a, **k: 0.0):
+    def deco(fn):
+        import functools
+
+        @functools.wraps(fn)
+        def wrapped(*a, **k):
+            rec = _PROFILE[0]
+            if rec is None:
+                return fn(*a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn(*a, **k)
+            e1.record()
+            rec.append((cls, e0, e1, float(work(*a, **k))))
+            return r
+        return wrapped
+    return deco
+
+
+def _conv_flops(x, wpack, bias=None, res=None, cout_blocks=1, **k):
+    return 2.0 * x.shape[0] * x.shape[1] * x.shape[2] * 96 * 96 * 9 * cout_blocks
+
+
+def _bytes_of(n_tensors):
+    return lambda c, *a, **k: float(n_tensors * c.numel() * 4)
+
+
 def _chk_nhwc(name: str, t: torch.Tensor) -> None:
     if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous() or t.dim() != 4 or t.shape[3] != 96 \
             or t.shape[1] != t.shape[2]:
@@ -207,6 +259,7 @@ def absmax(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+@_timed("conv3x3 forward / data gradient", _conv_flops)
 def conv3x3(x: torch.Tensor, wpack: torch.Tensor, bias: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
             cout_blocks: int = 1, shuffle: bool = False, scale_input: bool = False) -> torch.Tensor:
     """``conv(x) + bias [+ res]`` on NHWC fp32 (``F.conv2d(..., padding=1)``); with a mode-1 image: the data gradient.
@@ -291,6 +344,7 @@ def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, ws: Workspace, dw: Optional
     return out
 
 
+@_timed("conv3x3 weight gradient", lambda x, *a, **k: 2.0 * x.shape[0] * x.shape[1] * x.shape[2] * 96 * 96 * 9)
 def _conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, ws: Workspace, dw: Optional[torch.Tensor] = None,
                    db: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """(dw (96, 96, 3, 3), dbias (96,)) of ``F.conv2d(x, w, b, padding=1)`` given ``dy``; NHWC fp32 operands.  ``dw`` /
@@ -325,6 +379,7 @@ def _bn_scratch(ws: Workspace) -> torch.Tensor:
     return ws.get("bn", need.value)
 
 
+@_timed("BatchNorm forward (statistics + apply)", _bytes_of(3))
 def bn_train_fwd(c: torch.Tensor, gamma, beta, ws: Workspace, slope=None, res=None, res_factor: float = 0.0):
     """(out, batch_stats): ``res + res_factor * PReLU(bn(c))`` with batch statistics (``nn.BatchNorm2d`` in train mode)."""
     _chk_nhwc("c", c)
@@ -340,6 +395,7 @@ def bn_train_fwd(c: torch.Tensor, gamma, beta, ws: Workspace, slope=None, res=No
     return out, stats
 
 
+@_timed("BatchNorm backward", _bytes_of(5))
 def bn_train_bwd(c, dout, stats, gamma, beta, ws: Workspace, slope=None, dout_scale: float = 1.0, dgamma=None, dbeta=None,
                  dslope=None):
     """(dc, dgamma, dbeta, dslope | None) of ``PReLU(bn(c))`` in train mode given ``dout * dout_scale``.  ``dgamma`` /
@@ -366,6 +422,7 @@ def bn_train_bwd(c, dout, stats, gamma, beta, ws: Workspace, slope=None, dout_sc
     return dc, dgamma, dbeta, dslope
 
 
+@_timed("loss gradient")
 def pixel_loss_grad(sr: torch.Tensor, hr: torch.Tensor, ws: Workspace, w_l1: float = 1.0, w_ssim: float = 0.1) -> torch.Tensor:
     """d/dsr of ``w_l1 * weighted_l1(sr, hr) + w_ssim * (1 - ssim(sr, hr))`` (train.py:93; 0.3 / 1.0 at train.py:170-172)."""
     for name, t in (("sr", sr), ("hr", hr)):
@@ -477,6 +534,7 @@ def resblock_backward(dout: torch.Tensor, saved: dict, block: torch.nn.Module, w
 
 
 # ---- remaining layer types ------------------------------------------------------------------------------------------
+@_timed("scalar PReLU", _bytes_of(2))
 def prelu_scalar(x: torch.Tensor, slope: torch.Tensor) -> torch.Tensor:
     """``nn.PReLU()`` with one slope (Generator.py:51, 9, 70), out of place (the pre-activation is kept for the backward)."""
     y = torch.empty_like(x)
@@ -485,6 +543,7 @@ def prelu_scalar(x: torch.Tensor, slope: torch.Tensor) -> torch.Tensor:
     return y
 
 
+@_timed("scalar PReLU", _bytes_of(3))
 def prelu_scalar_bwd(x, dy, slope, ws: Workspace, dy2=None):
     """(dx, dslope (1,)) given the pre-activation ``x`` and ``dy`` (+ ``dy2``, a second consumer's gradient)."""
     need = ctypes.c_size_t()
@@ -499,6 +558,7 @@ def prelu_scalar_bwd(x, dy, slope, ws: Workspace, dy2=None):
     return dx, dslope
 
 
+@_timed("9x9 stem / head")
 def conv9x9_c3(img: torch.Tensor, wm: torch.Tensor, bias, out_hw: int, flip: bool) -> torch.Tensor:
     """out (n, out_hw, out_hw, 96) NHWC = bias + sum over the 243 taps of a 3-channel NCHW image times ``wm`` [243][96]."""
     n, c, ih, iw = img.shape
@@ -510,6 +570,7 @@ def conv9x9_c3(img: torch.Tensor, wm: torch.Tensor, bias, out_hw: int, flip: boo
     return out
 
 
+@_timed("9x9 stem / head")
 def conv9x9_c3_wgrad(act: torch.Tensor, img: torch.Tensor, ws: Workspace, flip: bool, want_bias: bool):
     """(r (96, 243), dbias (96,) | None): r[c][j] = sum over pixels act[..., c] * tap_j(img)."""
     _chk_nhwc("act", act)
@@ -560,6 +621,7 @@ def head_pack_split(w: torch.Tensor) -> torch.Tensor:
     return torch.cat([img.reshape(-1), tail.view(torch.float16)])
 
 
+@_timed("9x9 stem / head")
 def head_forward(v: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """``F.conv2d(v, w, b, padding=4)[:, :, :125, :125]`` (Generator.py:71,80): NHWC (n, 128, 128, 96) -> NCHW (n, 3, 125, 125)."""
     _chk_nhwc("v", v)
@@ -573,6 +635,7 @@ def head_forward(v: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Ten
     return y
 
 
+@_timed("channel attention", _bytes_of(3))
 def chan_attn_forward(x: torch.Tensor, ca: torch.nn.Module):
     """``x * sigmoid(fc(mean_hw(x)))`` (Generator.py:15-27): (y, saved)."""
     _chk_nhwc("x", x)
@@ -588,6 +651,7 @@ def chan_attn_forward(x: torch.Tensor, ca: torch.nn.Module):
     return y, {"x": x, "pool": pool, "scale": scale}
 
 
+@_timed("channel attention", _bytes_of(3))
 def chan_attn_backward(dy: torch.Tensor, saved: dict, ca: torch.nn.Module, ws: Workspace, into: Optional[dict] = None):
     x = saved["x"]
     n, dev = x.shape[0], x.device

@@ -137,3 +137,27 @@ def test_oracle_train_mode_forward_matches_reference_golden():
         assert np.abs(stats[k][0] - gt["mean1"][i]).max() <= 1e-6, k
         assert max_rel(stats[k][1], gt["var1"][i]) <= 1e-6, k
     assert len(stats) == 33
+
+
+def test_torch_restatement_of_the_training_steps_matches_reference_golden():
+    """oracle/torch_ref.py's pre-train step and GAN iteration (bench.py's cpu_baseline for configs[3] / [4]) against ONE step
+    of the real reference (tests/golden/train_step.npz, gan_step.npz: made by make_golden_bwd.py / make_golden_gan.py)."""
+    import os
+    from conftest import GOLDEN
+    from superresolution_amd import Discriminator
+    gs = np.load(os.path.join(GOLDEN, "train_step.npz"))
+    sd = W.synthetic_state_dict(0)
+    P = {k: v.clone().requires_grad_() for k, v in sd.items() if v.is_floating_point() and "running" not in k}
+    opt = torch.optim.AdamW(list(P.values()), lr=1e-4)
+    lr = torch.from_numpy(np.concatenate([W.synthetic_lr_batch(3, 2, "dense"), W.synthetic_lr_batch(1, 2, "sparse")], 0))
+    hr = torch.from_numpy(W.synthetic_hr_batch(4, seed=1))
+    loss = TR.pretrain_step(P, opt, lr, hr)
+    assert abs(loss - float(gs["loss"])) <= 1e-5 * abs(float(gs["loss"]))
+    gg = np.load(os.path.join(GOLDEN, "gan_step.npz"))
+    P = {k: v.clone().requires_grad_() for k, v in sd.items() if v.is_floating_point() and "running" not in k}
+    torch.manual_seed(3)
+    D = {k: v.detach().clone().requires_grad_() for k, v in Discriminator().named_parameters()}
+    opt_g, opt_d = torch.optim.AdamW(list(P.values()), lr=1e-4), torch.optim.AdamW(list(D.values()), lr=1e-6)
+    g_loss = TR.gan_iteration(P, D, opt_g, opt_d, torch.from_numpy(W.synthetic_lr_batch(2, 2, "dense")),
+                              torch.from_numpy(W.synthetic_hr_batch(2, seed=1)))
+    assert abs(g_loss - float(gg["g_loss"])) <= 2e-5 * abs(float(gg["g_loss"]))
