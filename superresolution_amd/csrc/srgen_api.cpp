@@ -347,6 +347,33 @@ std::vector<uint16_t> pack_head_bf16(const Folded& f)
     return p;
 }
 
+// split stem (srgen_stem_f32s.hip): 8-half units [ky 9][s 3][nt 3][hi | lo][lane 64]; lane l holds co = 32 nt + (l & 31),
+// element e -> kx = 4 s + 2 (l >> 5) + (e >> 2), ci = e & 3 (zero where kx >= 9 or ci == 3); then the amax tail
+std::vector<uint16_t> pack_stem_split_f16(const Folded& f)
+{
+    std::vector<uint16_t> p(kStemSplitHalfs + kSplitTailBytes / 2, 0);
+    auto bits = [](_Float16 v) { uint16_t u; memcpy(&u, &v, 2); return u; };
+    float amax = 0.f;
+    for (float v : f.w) amax = std::max(amax, std::fabs(v));
+    const float sc = pow2f(split_exp(amax));
+    for (int ky = 0; ky < 9; ++ky)
+        for (int s = 0; s < 3; ++s)
+            for (int nt = 0; nt < 3; ++nt)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 8; ++e) {
+                        const int kx = 4 * s + 2 * (lane >> 5) + (e >> 2), ci = e & 3, co = 32 * nt + (lane & 31);
+                        if (kx >= 9 || ci >= 3) continue;
+                        const float v = f.w[(((size_t)co * 3 + ci) * 9 + ky) * 9 + kx] * sc;
+                        const _Float16 hi = (_Float16)v;
+                        const _Float16 lo = (_Float16)(v - (float)hi);
+                        const size_t unit = ((((size_t)ky * 3 + s) * 3 + nt) * 2) * 64 + lane;
+                        p[unit * 8 + e] = bits(hi);
+                        p[(unit + 64) * 8 + e] = bits(lo);
+                    }
+    memcpy(&p[kStemSplitHalfs], &amax, 4);
+    return p;
+}
+
 // split head: 8-half units [g 6][ky 9][hi | lo][lane 64]; lane = 32 h + n, ci = 16 g + 8 h + e, n = kx*3 + co (< 27)
 std::vector<uint16_t> pack_head_split_f16(const Folded& f)
 {
@@ -525,7 +552,8 @@ int srgen_commit_weights(srgen_handle* h, void* stream)
     {   // stem: conv 9x9 + scalar PReLU                                   Generator.py:49-52
         Folded f = fold(h, "input.0", "", 1.0, 96, 3, 9);
         h->stem = ConvDev();
-        h->stem.w_f32 = blob.put_f32(pack_stem_f32(f));
+        if (h->f32_split) h->stem.w_split = blob.put_u16(pack_stem_split_f16(f));
+        else h->stem.w_f32 = blob.put_f32(pack_stem_f32(f));
         h->stem.w_bf16 = blob.put_u16(pack_stem_bf16(f));
         h->stem.bias = blob.put_f32(f.b);
         h->stem.slope = blob.put_f32(std::vector<float>(96, h->tensors.at("input.1.weight")[0]));
@@ -751,14 +779,19 @@ static int run_forward(srgen_handle* h, const void* x, void* y, void* workspace,
     };
 
     {   // x1 = input(x)                                                   Generator.py:75
-        StemArgs a{x, x1, B + (bf ? h->stem.w_bf16 : h->stem.w_f32), F(h->stem.bias), F(h->stem.slope), n};
+        const bool ssplit = !bf && h->f32_split;
+        StemArgs a{x, x1, B + (bf ? h->stem.w_bf16 : ssplit ? h->stem.w_split : h->stem.w_f32), F(h->stem.bias),
+                   F(h->stem.slope), n};
+        if (ssplit && !train && use_chain) {
+            // the stem's waves leave the per-image maxima of x1 in S(0) (atomic max: zero first); S(1) is what the first
+            // conv accumulates into.  The three arrays are consecutive in the workspace.
+            HIP_TRY(hipMemsetAsync(S(0), 0, ws.amax[2] - ws.amax[0], s));
+            a.out_amax = S(0);
+        }
         HIP_TRY(tick(SRGEN_K_STEM));
-        HIP_TRY(bf ? launch_stem_bf16(a, s) : launch_stem_f32(a, s));
+        HIP_TRY(bf ? launch_stem_bf16(a, s) : ssplit ? launch_stem_f32_split(a, s) : launch_stem_f32(a, s));
         HIP_TRY(tock());
         HIP_TRY(tap(0, x1, kLR * kLR));
-        if (!bf && h->f32_split && !train) {
-            HIP_TRY(launch_absmax_per_image((const float*)x1, n, (size_t)kLR * kLR * kC, S(0), S(1), s));
-        }
     }
     const void* cur = x1;                               // x2 = blocks(x1)  Generator.py:76
     int flip = 0;

@@ -95,6 +95,7 @@ struct StemArgs {
     const float* bias;     // [96]
     const float* slope;    // [96]
     int N;
+    float* out_amax = nullptr;   // split stem only: [N] device floats, zero on entry: max |out| per image (atomic max)
 };
 
 // ---- channel attention: pool finish + FC + sigmoid + in-place scale ---------------------
@@ -135,6 +136,9 @@ hipError_t launch_conv3x3_f32_split(const Conv3x3Args& a, hipStream_t s);
 hipError_t launch_conv3x3_f32_wino(const Conv3x3Args& a, hipStream_t s);
 constexpr size_t kWinoZeroBytes = 64 * 96 * 4;        // one 64-pixel row of 96 channels
 hipError_t launch_chan_attn_f32(const ChanAttnArgs& a, hipStream_t s);
+// the stem on the split path (srgen_stem_f32s.hip); wpack = f16 units [ky 9][s 3][nt 3][hi | lo][lane 64] + amax tail
+hipError_t launch_stem_f32_split(const StemArgs& a, hipStream_t s);
+constexpr size_t kStemSplitHalfs = (size_t)9 * 3 * 3 * 2 * 64 * 8;
 hipError_t launch_head_f32(const HeadArgs& a, hipStream_t s);
 // the head on the split path (srgen_head_f32s.hip); wpack = f16 units [chunk 6][ky 9][hi | lo][lane 64]
 hipError_t launch_head_f32_split(const HeadArgs& a, hipStream_t s);

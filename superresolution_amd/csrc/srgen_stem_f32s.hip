@@ -1,0 +1,149 @@
+// srgen_stem_f32s.hip -- gfx950 stem of the generator on the split arithmetic: Conv2d(3, 96, 9, padding=4) + PReLU()
+// (Generator.py:50-51) with fp32 tensors, fp32 accumulation and every product formed from two-term f16 splits of both
+// operands (three v_mfma_f32_32x32x16_f16 per product: srgen_conv3x3_f32s.hip explains the arithmetic and its error).
+//
+// K layout of the bf16 stem: per kernel row ky the taps kx = 0..11 (9 real) x ci = 0..3 (3 real) = 48 = three k16 steps, so
+// the 8 k-values of a lane are two neighbouring pixels of an HWC4 image of the input tile in LDS (two planes: high and low
+// parts).  The input tile is scaled by a power of two taken from ITS OWN maximum (exact, per workgroup: a workgroup only
+// ever multiplies the 12 x 64 input pixels it staged), the weights by the exponent in the image's tail.  Weights are the
+// MFMA A operand (rows = output channels), pixels the B operand: a lane ends with 4 consecutive channels of one pixel per
+// register group and stores 16-byte NHWC pieces straight from registers.  The epilogue also leaves the per-image maximum
+// of |output| (atomic max on the bit pattern) -- the bound the first 3x3 conv of the split path scales its input by, which
+// used to cost a pass of its own over the stem's output.
+#include "srgen_internal.h"
+
+namespace srgen {
+namespace sfs {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+
+#define MFMA_H(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+
+constexpr int ROWS = 12, RS = 76;                  // 4 + 8 halo rows; pixels per LDS row (4 + 64 + 8 reach)
+constexpr int PLANE = ROWS * RS * 8;               // bytes of one (high | low) HWC4 f16 plane: 7,296
+constexpr int PER_THREAD = 3 * ROWS * kLR / 256;   // input values per thread: 9
+
+__global__ __launch_bounds__(256, 2) void stem_f32s_kernel(StemArgs a)
+{
+    __shared__ __attribute__((aligned(16))) char lds[2 * PLANE];
+    __shared__ float red[4];
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, p = lane & 31;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ty = blockIdx.x % (kLR / 4), n = blockIdx.x / (kLR / 4);
+    const int y0 = ty * 4;
+    const float* x = (const float*)a.x + (size_t)n * 3 * kLR * kLR;
+
+    // ---- input tile: load, bound, split, HWC4 planes ------------------------------------------------------------------
+    float v[PER_THREAD];
+    float m = 0.f;
+#pragma unroll
+    for (int k = 0; k < PER_THREAD; ++k) {
+        const int i = tid + 256 * k;
+        const int gx = i & 63, r = (i >> 6) % ROWS, c = i / (64 * ROWS);
+        const int gy = y0 - 4 + r;
+        v[k] = (unsigned)gy < (unsigned)kLR ? x[((size_t)c * kLR + gy) * kLR + gx] : 0.f;
+        m = fmaxf(m, fabsf(v[k]));
+    }
+    for (int i = tid; i < 2 * PLANE / 4; i += 256) ((unsigned*)lds)[i] = 0u;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0) red[w] = m;
+    __syncthreads();
+    const int kx_in = __builtin_amdgcn_readfirstlane(split_exp(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
+    const int kw = split_tail_exp((const char*)a.wpack + (size_t)9 * 3 * 3 * 2 * 64 * 16, lane);
+    const float in_mul = pow2f(kx_in), out_mul = pow2f(-(kw + kx_in));
+    _Float16* const hi_plane = (_Float16*)lds;
+    _Float16* const lo_plane = (_Float16*)(lds + PLANE);
+#pragma unroll
+    for (int k = 0; k < PER_THREAD; ++k) {
+        const int i = tid + 256 * k;
+        const int gx = i & 63, r = (i >> 6) % ROWS, c = i / (64 * ROWS);
+        const float s = v[k] * in_mul;
+        const _Float16 hi = (_Float16)s;
+        hi_plane[(r * RS + gx + 4) * 4 + c] = hi;
+        lo_plane[(r * RS + gx + 4) * 4 + c] = (_Float16)(s - (float)hi);
+    }
+    __syncthreads();
+
+    f32x16 acc[2][3];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    // packed weights: 16-byte units [ky 9][s 3][nt 3][hi | lo][lane 64]: lane l holds w[co = 32 nt + (l & 31)][ci = e & 3]
+    // [ky][kx = 4 s + 2 (l >> 5) + (e >> 2)], zero at kx >= 9 and ci == 3
+    const h8* wp = (const h8*)a.wpack + lane;
+#pragma unroll
+    for (int ky = 0; ky < 9; ++ky) {
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const char* xb = lds + ((w + ky) * RS + p + 4 * s + 2 * h) * 8;
+            h8 xh[2], xl[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const h4 a0 = *(const h4*)(xb + 32 * 8 * mt), a1 = *(const h4*)(xb + 32 * 8 * mt + 8);
+                const h4 b0 = *(const h4*)(xb + PLANE + 32 * 8 * mt), b1 = *(const h4*)(xb + PLANE + 32 * 8 * mt + 8);
+                xh[mt] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+                xl[mt] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+            h8 wh[3], wl[3];
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt) {
+                wh[nt] = wp[(((ky * 3 + s) * 3 + nt) * 2 + 0) * 64];
+                wl[nt] = wp[(((ky * 3 + s) * 3 + nt) * 2 + 1) * 64];
+            }
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {          // small terms first
+                    acc[mt][nt] = MFMA_H(wl[nt], xh[mt], acc[mt][nt]);
+                    acc[mt][nt] = MFMA_H(wh[nt], xl[mt], acc[mt][nt]);
+                    acc[mt][nt] = MFMA_H(wh[nt], xh[mt], acc[mt][nt]);
+                }
+        }
+    }
+
+    // ---- epilogue (registers only): scale back, bias, PReLU, 16-byte NHWC stores, per-image maximum -----------------------
+    float* out = (float*)a.out + (((size_t)n * kLR + y0 + w) * kLR + p) * kC + 4 * h;
+    float vmax = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+        for (int G = 0; G < 4; ++G) {
+            const f32x4 b4 = *(const f32x4*)(a.bias + 32 * nt + 8 * G + 4 * h);
+            const f32x4 s4 = *(const f32x4*)(a.slope + 32 * nt + 8 * G + 4 * h);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t = acc[mt][nt][4 * G + e] * out_mul + b4[e];
+                    o[e] = t >= 0.f ? t : t * s4[e];
+                    vmax = fmaxf(vmax, fabsf(o[e]));
+                }
+                *(f32x4*)(out + (size_t)(32 * mt) * kC + 32 * nt + 8 * G) = o;
+            }
+        }
+    if (a.out_amax) {                                 // non-negative floats order like their bit patterns
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+        if (lane == 0 && vmax == vmax) atomicMax((unsigned*)a.out_amax + n, __float_as_uint(vmax));
+    }
+}
+
+}  // namespace sfs
+
+hipError_t launch_stem_f32_split(const StemArgs& a, hipStream_t s)
+{
+    if (a.N <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(sfs::stem_f32s_kernel, dim3((unsigned)(a.N * (kLR / 4))), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace srgen
