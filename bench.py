@@ -232,14 +232,19 @@ def training_object(workload, precision, dev, rank, n_ranks, use_dist, n=64, ste
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     # where the step's device time goes: three steps (one discriminator update among them for cfg4) on ONE stream, every
-    # operator call between two HIP events
+    # operator call between two HIP events; done twice, each class taking the smaller of its two sums (a one-off stall of
+    # the host inside one call -- an allocator growth, the event pool -- otherwise lands on whichever class it hit)
     side, owner.side = owner.side, None
     try:
-        with T.profile_ops() as prof:
-            for _ in range(3):
-                run()
+        rounds = []
+        for _ in range(2):
+            with T.profile_ops() as pr:
+                for _ in range(3):
+                    run()
+            rounds.append(pr)
     finally:
         owner.side = side
+    prof = {k: min((r[k] for r in rounds if k in r), key=lambda v: v[0]) for k in rounds[0]}
     total = sum(v[0] for v in prof.values()) or 1.0
     classes = {k: {"ms_per_step": round(v[0] / 3, 3), "launches_per_step": round(v[1] / 3, 1), "share": round(v[0] / total, 3)}
                for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}

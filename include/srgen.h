@@ -282,6 +282,12 @@ SRGEN_API int srgen_prelu_scalar_bwd(const float* x, const float* dy, const floa
  *       flip 1: weight gradient of the head (act = the head's input, img = d out): r[ci][(co,ky,kx)] = dw[co][ci][ky][kx] */
 SRGEN_API int srgen_conv9x9_c3_nhwc(const float* img, const float* wm, const float* bias, float* out, int n, int ih,
                                     int iw, int oh, int ow, int flip, void* stream);
+/* srgen_conv9x9_c3_nhwc on the split arithmetic (fp32 products from two-term f16 splits, srgen_stem_f32s.hip: the kernel
+ * of the eval forward's stem): same arguments and result to fp32 rounding; oh a multiple of 4, ow of 64; the weight
+ * image is made on the device from wm on every call into wpack_scratch (>= 165,888 + 128 bytes, 16-byte aligned). */
+SRGEN_API int srgen_conv9x9_c3_nhwc_split(const float* img, const float* wm, const float* bias, float* out, int n, int ih,
+                                          int iw, int oh, int ow, int flip, void* wpack_scratch, size_t wpack_scratch_bytes,
+                                          void* stream);
 SRGEN_API int srgen_conv9x9_c3_wgrad_scratch_bytes(int n, int ah, size_t* bytes);
 SRGEN_API int srgen_conv9x9_c3_wgrad(const float* act, const float* img, int n, int ah, int aw, int ih, int iw, int flip,
                                      float* r, float* dbias, void* scratch, size_t scratch_bytes, void* stream);

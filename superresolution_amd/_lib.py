@@ -103,6 +103,7 @@ def lib() -> ctypes.CDLL:
     L.srgen_prelu_scalar_fwd.argtypes = [vp, vp, vp, sz, vp]
     L.srgen_prelu_scalar_bwd.argtypes = [vp, vp, vp, vp, vp, vp, sz, vp, sz, vp]
     L.srgen_conv9x9_c3_nhwc.argtypes = [vp, vp, vp, vp, i, i, i, i, i, i, vp]
+    L.srgen_conv9x9_c3_nhwc_split.argtypes = [vp, vp, vp, vp, i, i, i, i, i, i, vp, sz, vp]
     L.srgen_conv9x9_c3_wgrad_scratch_bytes.argtypes = [i, i, ctypes.POINTER(sz)]
     L.srgen_conv9x9_c3_wgrad.argtypes = [vp, vp, i, i, i, i, i, i, vp, vp, vp, sz, vp]
     L.srgen_head_nhwc.argtypes = [vp, vp, vp, vp, i, vp]
@@ -131,7 +132,7 @@ def lib() -> ctypes.CDLL:
                  "srdisc_stem_dgrad", "srdisc_tail_bwd", "srgen_ragan_loss_grad", "srgen_clip_grad_norm_scratch_bytes",
                  "srgen_clip_grad_norm"):
         getattr(L, name).restype = i
-    for name in ("srgen_prelu_scratch_bytes", "srgen_prelu_scalar_fwd", "srgen_prelu_scalar_bwd", "srgen_conv9x9_c3_nhwc",
+    for name in ("srgen_prelu_scratch_bytes", "srgen_prelu_scalar_fwd", "srgen_prelu_scalar_bwd", "srgen_conv9x9_c3_nhwc", "srgen_conv9x9_c3_nhwc_split",
                  "srgen_conv9x9_c3_wgrad_scratch_bytes", "srgen_conv9x9_c3_wgrad", "srgen_head_nhwc", "srgen_head_nhwc_split", "srgen_chan_attn_nhwc",
                  "srgen_chan_attn_bwd_scratch_bytes", "srgen_chan_attn_bwd"):
         getattr(L, name).restype = i

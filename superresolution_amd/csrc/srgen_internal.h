@@ -139,6 +139,20 @@ hipError_t launch_chan_attn_f32(const ChanAttnArgs& a, hipStream_t s);
 // the stem on the split path (srgen_stem_f32s.hip); wpack = f16 units [ky 9][s 3][nt 3][hi | lo][lane 64] + amax tail
 hipError_t launch_stem_f32_split(const StemArgs& a, hipStream_t s);
 constexpr size_t kStemSplitHalfs = (size_t)9 * 3 * 3 * 2 * 64 * 8;
+// the same kernel for any 3-channel NCHW image (ih x iw, zero outside) and an NHWC output of oh x ow (multiples of 4 / 64);
+// bias, slope, out_amax may be nullptr
+struct Stem9Args {
+    const float* x;
+    float* out;
+    const void* wpack;
+    const float* bias;
+    const float* slope;
+    int N, ih, iw, oh, ow;
+    float* out_amax;
+};
+hipError_t launch_conv9x9_c3_split(const Stem9Args& a, hipStream_t s);
+// weight image (kStemSplitHalfs halfs + kSplitTailBytes) from the tap matrix wm[243][96] on the device
+hipError_t launch_stem_split_pack(const float* wm, int flip, void* out, hipStream_t s);
 hipError_t launch_head_f32(const HeadArgs& a, hipStream_t s);
 // the head on the split path (srgen_head_f32s.hip); wpack = f16 units [chunk 6][ky 9][hi | lo][lane 64]
 hipError_t launch_head_f32_split(const HeadArgs& a, hipStream_t s);

@@ -10,6 +10,11 @@
 // register group and stores 16-byte NHWC pieces straight from registers.  The epilogue also leaves the per-image maximum
 // of |output| (atomic max on the bit pattern) -- the bound the first 3x3 conv of the split path scales its input by, which
 // used to cost a pass of its own over the stem's output.
+//
+// The same kernel serves the training step's 9x9 convs against a 3-channel image (srgen_conv9x9_c3_nhwc: the stem forward
+// from the live weights, and the head's data gradient -- d out (125 x 125) against the flipped head weights at 128 x 128):
+// any input size (zero outside), output a multiple of 4 rows x 64 columns, optional bias / PReLU, and a weight image packed
+// on the device from the [243][96] tap matrix (stem_split_pack_kernel; the flip is a permutation of the taps there).
 #include "srgen_internal.h"
 
 namespace srgen {
@@ -24,47 +29,55 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
 constexpr int ROWS = 12, RS = 76;                  // 4 + 8 halo rows; pixels per LDS row (4 + 64 + 8 reach)
 constexpr int PLANE = ROWS * RS * 8;               // bytes of one (high | low) HWC4 f16 plane: 7,296
-constexpr int PER_THREAD = 3 * ROWS * kLR / 256;   // input values per thread: 9
+constexpr int NVAL = 3 * ROWS * RS;                // input values of a tile: 2,736
+constexpr int PER_THREAD = (NVAL + 255) / 256;     // ... per thread: 11
 
-__global__ __launch_bounds__(256, 2) void stem_f32s_kernel(StemArgs a)
+__global__ __launch_bounds__(256, 2) void stem_f32s_kernel(Stem9Args a)
 {
     __shared__ __attribute__((aligned(16))) char lds[2 * PLANE];
     __shared__ float red[4];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, p = lane & 31;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ty = blockIdx.x % (kLR / 4), n = blockIdx.x / (kLR / 4);
-    const int y0 = ty * 4;
-    const float* x = (const float*)a.x + (size_t)n * 3 * kLR * kLR;
+    const int tiles_x = a.ow >> 6, tiles_y = a.oh >> 2;
+    int b = blockIdx.x;
+    const int tx = b % tiles_x;
+    b /= tiles_x;
+    const int ty = b % tiles_y, n = b / tiles_y;
+    const int y0 = ty * 4, x0 = tx * 64;
+    const float* x = a.x + (size_t)n * 3 * a.ih * a.iw;
 
-    // ---- input tile: load, bound, split, HWC4 planes ------------------------------------------------------------------
+    // ---- input tile (12 rows x 76 columns x 3 channels, zero outside the image): load, bound, split, HWC4 planes ------
     float v[PER_THREAD];
     float m = 0.f;
 #pragma unroll
     for (int k = 0; k < PER_THREAD; ++k) {
         const int i = tid + 256 * k;
-        const int gx = i & 63, r = (i >> 6) % ROWS, c = i / (64 * ROWS);
-        const int gy = y0 - 4 + r;
-        v[k] = (unsigned)gy < (unsigned)kLR ? x[((size_t)c * kLR + gy) * kLR + gx] : 0.f;
+        const int cc = i % RS, r = (i / RS) % ROWS, c = i / (RS * ROWS);
+        const int gy = y0 - 4 + r, gx = x0 - 4 + cc;
+        const bool ok = i < NVAL && (unsigned)gy < (unsigned)a.ih && (unsigned)gx < (unsigned)a.iw;
+        v[k] = ok ? x[((size_t)c * a.ih + gy) * a.iw + gx] : 0.f;
         m = fmaxf(m, fabsf(v[k]));
     }
-    for (int i = tid; i < 2 * PLANE / 4; i += 256) ((unsigned*)lds)[i] = 0u;
+    for (int i = tid; i < 2 * PLANE / 4; i += 256) ((unsigned*)lds)[i] = 0u;          // (the unused fourth channel must be 0)
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     if (lane == 0) red[w] = m;
     __syncthreads();
     const int kx_in = __builtin_amdgcn_readfirstlane(split_exp(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
-    const int kw = split_tail_exp((const char*)a.wpack + (size_t)9 * 3 * 3 * 2 * 64 * 16, lane);
+    const int kw = split_tail_exp((const char*)a.wpack + kStemSplitHalfs * 2, lane);
     const float in_mul = pow2f(kx_in), out_mul = pow2f(-(kw + kx_in));
     _Float16* const hi_plane = (_Float16*)lds;
     _Float16* const lo_plane = (_Float16*)(lds + PLANE);
 #pragma unroll
     for (int k = 0; k < PER_THREAD; ++k) {
         const int i = tid + 256 * k;
-        const int gx = i & 63, r = (i >> 6) % ROWS, c = i / (64 * ROWS);
-        const float s = v[k] * in_mul;
-        const _Float16 hi = (_Float16)s;
-        hi_plane[(r * RS + gx + 4) * 4 + c] = hi;
-        lo_plane[(r * RS + gx + 4) * 4 + c] = (_Float16)(s - (float)hi);
+        if (i < NVAL) {
+            const int cc = i % RS, r = (i / RS) % ROWS, c = i / (RS * ROWS);
+            const float s = v[k] * in_mul;
+            const _Float16 hi = (_Float16)s;
+            hi_plane[(r * RS + cc) * 4 + c] = hi;
+            lo_plane[(r * RS + cc) * 4 + c] = (_Float16)(s - (float)hi);
+        }
     }
     __syncthreads();
 
@@ -110,14 +123,15 @@ __global__ __launch_bounds__(256, 2) void stem_f32s_kernel(StemArgs a)
     }
 
     // ---- epilogue (registers only): scale back, bias, PReLU, 16-byte NHWC stores, per-image maximum -----------------------
-    float* out = (float*)a.out + (((size_t)n * kLR + y0 + w) * kLR + p) * kC + 4 * h;
+    float* out = a.out + (((size_t)n * a.oh + y0 + w) * a.ow + x0 + p) * kC + 4 * h;
     float vmax = 0.f;
 #pragma unroll
     for (int nt = 0; nt < 3; ++nt)
 #pragma unroll
         for (int G = 0; G < 4; ++G) {
-            const f32x4 b4 = *(const f32x4*)(a.bias + 32 * nt + 8 * G + 4 * h);
-            const f32x4 s4 = *(const f32x4*)(a.slope + 32 * nt + 8 * G + 4 * h);
+            f32x4 b4 = {0.f, 0.f, 0.f, 0.f}, s4 = {1.f, 1.f, 1.f, 1.f};
+            if (a.bias) b4 = *(const f32x4*)(a.bias + 32 * nt + 8 * G + 4 * h);
+            if (a.slope) s4 = *(const f32x4*)(a.slope + 32 * nt + 8 * G + 4 * h);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 f32x4 o;
@@ -137,12 +151,68 @@ __global__ __launch_bounds__(256, 2) void stem_f32s_kernel(StemArgs a)
     }
 }
 
+// Weight image of the kernel above from the tap matrix wm[j = (ci, ky, kx)][96] (fp32, on the device): one workgroup finds
+// max |w|, then writes the units [ky' 9][s 3][nt 3][hi | lo][lane 64] (element e of lane l: kx' = 4 s + 2 (l >> 5) + (e >> 2),
+// ci = e & 3, co = 32 nt + (l & 31); zero where kx' >= 9 or ci == 3) and the tail.  flip: position (ky', kx') carries tap
+// (8 - ky', 8 - kx') -- the correlation with the flipped kernel that conv9x9_c3 calls flip = 1.
+constexpr int PACK_UNITS = 9 * 3 * 3 * 64;            // (ky', s, nt, lane); each has a high and a low unit
+__global__ __launch_bounds__(256) void stem_split_pack_kernel(const float* __restrict__ wm, int flip, _Float16* __restrict__ out)
+{
+    __shared__ float red[4];
+    const int tid = threadIdx.x;
+    float m = 0.f;                                        // every workgroup finds max |w| for itself (93 KB, cache resident)
+    for (int i = tid; i < 243 * 96 / 4; i += 256) {
+        const f32x4 q = *(const f32x4*)(wm + 4 * i);
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(q.x), fabsf(q.y))), fmaxf(fabsf(q.z), fabsf(q.w)));
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float sc = pow2f(split_exp(m));
+    const int u = blockIdx.x * 256 + tid;
+    if (u < PACK_UNITS) {
+        const int lane = u & 63, nt = (u >> 6) % 3, s = (u / 192) % 3, kyp = u / 576;
+        h8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int kxp = 4 * s + 2 * (lane >> 5) + (e >> 2), ci = e & 3, co = 32 * nt + (lane & 31);
+            float v = 0.f;
+            if (kxp < 9 && ci < 3) {
+                const int ky = flip ? 8 - kyp : kyp, kx = flip ? 8 - kxp : kxp;
+                v = wm[(size_t)(ci * 81 + ky * 9 + kx) * 96 + co] * sc;
+            }
+            hi[e] = (_Float16)v;
+            lo[e] = (_Float16)(v - (float)hi[e]);
+        }
+        const size_t unit = ((((size_t)kyp * 3 + s) * 3 + nt) * 2) * 64 + lane;
+        *(h8*)(out + unit * 8) = hi;
+        *(h8*)(out + (unit + 64) * 8) = lo;
+    }
+    if (blockIdx.x == 0 && tid < 32) ((float*)(out + kStemSplitHalfs))[tid] = tid == 0 ? m : 0.f;
+}
+
 }  // namespace sfs
+
+hipError_t launch_conv9x9_c3_split(const Stem9Args& a, hipStream_t s)
+{
+    if (a.N <= 0 || a.ih <= 0 || a.iw <= 0 || a.oh <= 0 || a.ow <= 0 || (a.oh & 3) || (a.ow & 63)) return hipErrorInvalidValue;
+    const long long blocks = (long long)a.N * (a.oh >> 2) * (a.ow >> 6);
+    if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(sfs::stem_f32s_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
 
 hipError_t launch_stem_f32_split(const StemArgs& a, hipStream_t s)
 {
-    if (a.N <= 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(sfs::stem_f32s_kernel, dim3((unsigned)(a.N * (kLR / 4))), dim3(256), 0, s, a);
+    Stem9Args g{(const float*)a.x, (float*)a.out, a.wpack, a.bias, a.slope, a.N, kLR, kLR, kLR, kLR, a.out_amax};
+    return launch_conv9x9_c3_split(g, s);
+}
+
+hipError_t launch_stem_split_pack(const float* wm, int flip, void* out, hipStream_t s)
+{
+    hipLaunchKernelGGL(sfs::stem_split_pack_kernel, dim3((sfs::PACK_UNITS + 255) / 256), dim3(256), 0, s, wm, flip, (_Float16*)out);
     return hipGetLastError();
 }
 

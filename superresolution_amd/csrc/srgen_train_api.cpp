@@ -299,6 +299,20 @@ int srgen_conv9x9_c3_nhwc(const float* img, const float* wm, const float* bias, 
     return SRGEN_OK;
 }
 
+int srgen_conv9x9_c3_nhwc_split(const float* img, const float* wm, const float* bias, float* out, int n, int ih, int iw, int oh,
+                                int ow, int flip, void* wpack_scratch, size_t wpack_scratch_bytes, void* stream)
+{
+    if (!img || !wm || !out || !wpack_scratch) return fail(SRGEN_E_INVALID, "NULL argument");
+    if (n <= 0 || ih <= 0 || iw <= 0 || oh <= 0 || ow <= 0) return fail(SRGEN_E_INVALID, "bad shape");
+    if ((oh & 3) || (ow & 63)) return fail(SRGEN_E_UNSUPPORTED, "output must be a multiple of 4 rows x 64 columns, got %d x %d", oh, ow);
+    if (wpack_scratch_bytes < kStemSplitHalfs * 2 + kSplitTailBytes) return fail(SRGEN_E_WORKSPACE, "weight-image scratch too small");
+    if (!aligned16(out) || !aligned16(bias) || !aligned16(wpack_scratch)) return fail(SRGEN_E_INVALID, "out / bias / scratch must be 16-byte aligned");
+    HIP_TRY(launch_stem_split_pack(wm, flip ? 1 : 0, wpack_scratch, (hipStream_t)stream));
+    Stem9Args a{img, out, wpack_scratch, bias, nullptr, n, ih, iw, oh, ow, nullptr};
+    HIP_TRY(launch_conv9x9_c3_split(a, (hipStream_t)stream));
+    return SRGEN_OK;
+}
+
 int srgen_conv9x9_c3_wgrad_scratch_bytes(int n, int ah, size_t* bytes)
 {
     if (!bytes || n <= 0 || ah <= 0) return fail(SRGEN_E_INVALID, "bad argument");

@@ -269,6 +269,7 @@ class GanStep:
         del S
         hr = hr_img.detach().to(torch.float32)
         n = hr.shape[0]
+        self.opt_d.restore_grad_views()
         self.opt_d.zero_grad()
         logits, saved = self.dgrad.forward(torch.cat([hr, fake.to(torch.float32)], 0))
         real_logits, fake_logits = logits[:n].contiguous(), logits[n:].contiguous()
@@ -293,6 +294,7 @@ class GanStep:
         if not self.gen.g.training:
             raise RuntimeError("GanStep runs the generator in train mode (train.py:132): call generator.train()")
         hr = hr_img.detach().to(torch.float32).contiguous()
+        self.opt_g.restore_grad_views()
         self.opt_g.zero_grad()
         kept, self._kept_forward = self._kept_forward, None
         sr, S = kept if kept is not None else self.gen.forward(lr_img)

@@ -24,6 +24,7 @@ WINO_FLOATS = 16 * 96 * 96           # Winograd weight image of one 96 -> 96 con
 SPLIT_HALFS = 2 * 9 * 96 * 96         # split-f16 weight image of one 96 -> 96 conv: (hi, lo) per weight
 AMAX_SLOTS = 1024                     # SRGEN_AMAX_SLOTS (include/srgen.h)
 SPLIT_TAIL_HALFS = 64                 # ... and its 128-byte tail: 32 partial maxima of |w| (the weights' scale)
+STEM_SPLIT_BYTES = 9 * 3 * 3 * 2 * 64 * 16 + 128     # split-f16 weight image of a 9x9 conv against a 3-channel image
 
 
 def _stream(t: torch.Tensor) -> int:
@@ -459,12 +460,14 @@ class FlatAdamW(torch.optim.Optimizer):
         self.flat_grad = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg, self.exp_avg_sq = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
         off = 0
+        self._grad_views = []
         with torch.no_grad():
             for p in plist:
                 k = p.numel()
                 self.flat[off:off + k].copy_(p.detach().reshape(-1))
                 p.data = self.flat[off:off + k].view(p.shape)
                 p.grad = self.flat_grad[off:off + k].view(p.shape)
+                self._grad_views.append(p.grad)
                 off += k
         self.steps = 0
 
@@ -486,17 +489,69 @@ class FlatAdamW(torch.optim.Optimizer):
         # Discriminator mirrors watch to re-fold and re-upload their weights before the next eval forward
         torch.autograd.graph.increment_version(self.params)
 
+    def restore_grad_views(self) -> None:
+        """Re-point every ``p.grad`` at its view of ``flat_grad`` where it is something else (``nn.Module.zero_grad()`` /
+        ``zero_grad(set_to_none=True)`` of a stock optimizer set them to None; a gradient tensor someone assigned is
+        copied in).  One identity check per parameter when nothing changed."""
+        views = self._grad_views
+        if all(p.grad is v for p, v in zip(self.params, views)):
+            return
+        for p, v in zip(self.params, views):
+            if p.grad is not v:
+                if p.grad is not None:
+                    v.copy_(p.grad)
+                p.grad = v
+
     def state_dict(self) -> dict:
+        """``torch.optim.AdamW.state_dict()``'s layout -- per-parameter ``step`` / ``exp_avg`` / ``exp_avg_sq`` under
+        ``state`` and the hyper-parameters under ``param_groups`` -- so that the ``opt_g`` / ``opt_d`` entries of the
+        reference's ``epoch_XXX.pt`` checkpoints (train.py:219-225) can be exchanged with a stock AdamW in both directions."""
         g = {k: v for k, v in self.param_groups[0].items() if k != "params"}
-        return {"step": self.steps, "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(), "param_groups": [g]}
+        g["params"] = list(range(len(self.params)))
+        state, off = {}, 0
+        if self.steps > 0:
+            for i, p in enumerate(self.params):
+                k = p.numel()
+                state[i] = {"step": torch.tensor(float(self.steps)),
+                            "exp_avg": self.exp_avg[off:off + k].view(p.shape).clone(),
+                            "exp_avg_sq": self.exp_avg_sq[off:off + k].view(p.shape).clone()}
+                off += k
+        return {"state": state, "param_groups": [g]}
 
     def load_state_dict(self, sd: dict) -> None:
-        if sd["exp_avg"].numel() != self.flat.numel():
-            raise ValueError(f"optimizer state has {sd['exp_avg'].numel()} entries, the parameters {self.flat.numel()}")
-        self.steps = int(sd["step"])
-        self.exp_avg.copy_(sd["exp_avg"])
-        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
-        self.param_groups[0].update(sd["param_groups"][0])
+        """Takes ``torch.optim.AdamW.state_dict()`` (and what ``state_dict`` above returns); the flat layout of earlier
+        versions of this class ({'step', 'exp_avg', 'exp_avg_sq', 'param_groups'}) is still read."""
+        if "state" not in sd:                                            # (the former private layout)
+            if sd["exp_avg"].numel() != self.flat.numel():
+                raise ValueError(f"optimizer state has {sd['exp_avg'].numel()} entries, the parameters {self.flat.numel()}")
+            self.steps = int(sd["step"])
+            self.exp_avg.copy_(sd["exp_avg"])
+            self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+            self.param_groups[0].update({k: v for k, v in sd["param_groups"][0].items() if k != "params"})
+            return
+        groups = sd["param_groups"]
+        ids = [i for g in groups for i in g["params"]]
+        if len(groups) != 1 or len(ids) != len(self.params):
+            raise ValueError(f"optimizer state describes {len(ids)} parameters in {len(groups)} group(s); this optimizer "
+                             f"holds {len(self.params)} in one")
+        state = sd["state"]
+        steps = {int(float(st["step"])) for st in state.values()}
+        if len(steps) > 1:
+            raise ValueError(f"per-parameter step counts differ ({sorted(steps)}): one flat AdamW has one step count")
+        self.steps = steps.pop() if steps else 0
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        off = 0
+        for i, p in zip(ids, self.params):
+            k = p.numel()
+            st = state.get(i)
+            if st is not None:
+                if st["exp_avg"].numel() != k:
+                    raise ValueError(f"optimizer state of parameter {i} has {st['exp_avg'].numel()} entries, the parameter {k}")
+                self.exp_avg[off:off + k].copy_(st["exp_avg"].reshape(-1))
+                self.exp_avg_sq[off:off + k].copy_(st["exp_avg_sq"].reshape(-1))
+            off += k
+        self.param_groups[0].update({k: v for k, v in groups[0].items() if k != "params"})
 
 
 # ---- the residual block (Generator.py:30-42) in train mode: forward with saved tensors, backward ----------------------
@@ -564,9 +619,17 @@ def conv9x9_c3(img: torch.Tensor, wm: torch.Tensor, bias, out_hw: int, flip: boo
     n, c, ih, iw = img.shape
     assert c == 3 and img.is_contiguous() and wm.shape == (243, 96) and wm.is_contiguous()
     out = torch.empty((n, out_hw, out_hw, 96), dtype=torch.float32, device=img.device)
+    pb = bias.data_ptr() if bias is not None else None
     with torch.cuda.device(img.device):
-        _lib.check(_lib.lib().srgen_conv9x9_c3_nhwc(img.data_ptr(), wm.data_ptr(), bias.data_ptr() if bias is not None else None,
-                                                    out.data_ptr(), n, ih, iw, out_hw, out_hw, 1 if flip else 0, _stream(img)))
+        if conv_path() == "split" and out_hw % 64 == 0:
+            # the eval stem's kernel (three f16 MFMAs per product, the input tile scaled by its own maximum, so gradients
+            # of any magnitude keep fp32 accuracy); its weight image is made from wm on the device
+            pack = torch.empty(STEM_SPLIT_BYTES, dtype=torch.uint8, device=img.device)
+            _lib.check(_lib.lib().srgen_conv9x9_c3_nhwc_split(img.data_ptr(), wm.data_ptr(), pb, out.data_ptr(), n, ih, iw, out_hw,
+                                                              out_hw, 1 if flip else 0, pack.data_ptr(), pack.numel(), _stream(img)))
+        else:
+            _lib.check(_lib.lib().srgen_conv9x9_c3_nhwc(img.data_ptr(), wm.data_ptr(), pb, out.data_ptr(), n, ih, iw, out_hw, out_hw,
+                                                        1 if flip else 0, _stream(img)))
     return out
 
 
@@ -865,6 +928,7 @@ class PretrainStep(GeneratorGrad):
         if not self.g.training:
             raise RuntimeError("PretrainStep runs the generator in train mode (train.py:81): call generator.train()")
         hr = hr_img.detach().to(torch.float32).contiguous()
+        self.optimizer.restore_grad_views()                # (a module-level zero_grad() may have dropped them)
         with conv_precision(resolve_precision(self.precision)), packed_weights(self.pack_jobs()):
             sr, S = self.forward(lr_img)
             vals = pixel_losses(sr, hr)                                     # [psnr, ssim, l1, weighted_l1]

@@ -279,6 +279,48 @@ def test_flat_adamw_vs_reference_golden(gold):
     assert torch.equal(p.detach(), p2.detach())                    # resumed optimizer continues bit for bit
 
 
+def test_flat_adamw_exchanges_state_with_torch_adamw():
+    """The reference checkpoints `opt_g.state_dict()` of a torch.optim.AdamW (train.py:219-225): FlatAdamW reads that layout
+    and writes it, and a module-level zero_grad() (gradients set to None) does not break the flat gradient views."""
+    from superresolution_amd import training as T
+    shapes = [(33, 7), (5,), (2, 3, 3, 3)]
+    base = [_hash_tensor(70 + i, "xch.p", s) for i, s in enumerate(shapes)]
+    grads = [[_hash_tensor(80 + 10 * k + i, "xch.g", s, -0.05, 0.05) for i, s in enumerate(shapes)] for k in range(3)]
+    tp = [torch.nn.Parameter(b.clone().cuda()) for b in base]
+    topt = torch.optim.AdamW(tp, lr=1e-3)
+    fp = [torch.nn.Parameter(b.clone().cuda()) for b in base]
+    fopt = T.FlatAdamW(fp, lr=1e-3)
+
+    def step(opt, ps, k):
+        for p, g in zip(ps, grads[k]):
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+            p.grad.copy_(g.cuda())
+        opt.step()
+
+    step(topt, tp, 0)
+    fopt.load_state_dict(topt.state_dict())                  # torch -> flat, after one torch step
+    with torch.no_grad():
+        for p, q in zip(fp, tp):
+            p.copy_(q)
+    for p in fp:
+        p.grad = None                                        # what nn.Module.zero_grad() leaves
+    fopt.restore_grad_views()
+    assert fp[0].grad.data_ptr() == fopt.flat_grad.data_ptr()
+    step(topt, tp, 1)
+    step(fopt, fp, 1)
+    for p, q in zip(fp, tp):
+        assert float((p.detach() - q.detach()).abs().max()) <= 2e-7
+    tp2 = [torch.nn.Parameter(p.detach().clone()) for p in fp]
+    topt2 = torch.optim.AdamW(tp2, lr=1e-3)
+    topt2.load_state_dict(fopt.state_dict())                 # flat -> torch
+    step(topt2, tp2, 2)
+    step(fopt, fp, 2)
+    for p, q in zip(fp, tp2):
+        assert float((p.detach() - q.detach()).abs().max()) <= 2e-7
+    assert int(float(topt2.state_dict()["state"][0]["step"])) == 3 and fopt.steps == 3
+
+
 # ---- the whole pre-train step (train.py:90-97) ----------------------------------------------------------------------
 # Gradients at the far end of the 39-layer backward chain carry the rounding of both fp32 computations (and the odd
 # PReLU pre-activation that rounds to opposite sides of 0): measured worst 2.5e-4 of max|gradient| at the stem weight,
