@@ -768,21 +768,34 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* __restri
         const size_t per = (npix + gridDim.x - 1) / gridDim.x;
         const size_t p0 = (size_t)blockIdx.x * per, p1 = p0 + per < npix ? p0 + per : npix;
         float s_dz[4] = {0, 0, 0, 0}, s_dzx[4] = {0, 0, 0, 0}, s_sl[4] = {0, 0, 0, 0};
-        for (size_t p = p0 + row; p < p1; p += 10) {
-            const f32x4 cv = *(const f32x4*)(c + p * 96 + c4 * 4);
-            const f32x4 dv = *(const f32x4*)(dt + p * 96 + c4 * 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float xh = fmaf(cv[e], rstd[e], -mr[e]);
-                const float z = fmaf(cv[e], pp[e], qq[e]);
-                const float d = dv[e] * dscale;
-                const bool neg = slope && z < 0.f;
-                const float dz = neg ? d * sl[e] : d;
-                s_dz[e] += dz;
-                s_dzx[e] += dz * xh;
-                if (neg) s_sl[e] += d * z;
+        const float* cp = c + (p0 + row) * 96 + c4 * 4;
+        const float* dp = dt + (p0 + row) * 96 + c4 * 4;
+        const int iters = p1 > p0 + row ? (int)((p1 - p0 - row + 9) / 10) : 0;     // pixels of this thread
+        int it = 0;
+        for (; it + 4 <= iters; it += 4) {
+            f32x4 cv0 = *(const f32x4*)(cp), cv1 = *(const f32x4*)(cp + 960), cv2 = *(const f32x4*)(cp + 1920), cv3 = *(const f32x4*)(cp + 2880);
+            f32x4 dv0 = *(const f32x4*)(dp), dv1 = *(const f32x4*)(dp + 960), dv2 = *(const f32x4*)(dp + 1920), dv3 = *(const f32x4*)(dp + 2880);
+            cp += 3840; dp += 3840;
+#define BNB_ADD(cv, dv)                                                     \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                 \
+                const float xh = fmaf(cv[e], rstd[e], -mr[e]);              \
+                const float z = fmaf(cv[e], pp[e], qq[e]);                  \
+                const float d = dv[e] * dscale;                             \
+                const bool neg = slope && z < 0.f;                          \
+                const float dz = neg ? d * sl[e] : d;                       \
+                s_dz[e] += dz;                                              \
+                s_dzx[e] += dz * xh;                                        \
+                s_sl[e] += neg ? d * z : 0.f;                               \
             }
+            BNB_ADD(cv0, dv0) BNB_ADD(cv1, dv1) BNB_ADD(cv2, dv2) BNB_ADD(cv3, dv3)
         }
+        for (; it < iters; ++it) {
+            const f32x4 cv = *(const f32x4*)(cp);
+            const f32x4 dv = *(const f32x4*)(dp);
+            cp += 960; dp += 960;
+            BNB_ADD(cv, dv)
+        }
+#undef BNB_ADD
         for (int e = 0; e < 4; ++e) {
             red[row][0][c4 * 4 + e] = (double)s_dz[e];
             red[row][1][c4 * 4 + e] = (double)s_dzx[e];
