@@ -197,7 +197,8 @@ def training_object(workload, precision, dev, rank, n_ranks, use_dist, n=64, ste
         step = T.PretrainStep(g, lr=1e-4, precision=precision)
         owner = step
         run = lambda: step.step(lr, hr)
-        name = f"BASELINE.json configs[3]: pre-train step (forward, loss, backward, AdamW), {n} images per GPU, fp32 tensors"
+        name = (f"BASELINE.json configs[3]: pre-train step (forward, loss, backward, AdamW), {n} images per GPU, "
+                f"{'bf16' if precision == 'bf16' else 'fp32'} tensors")
         metric = "pre-train step images/s"
     else:
         torch.manual_seed(3)
@@ -210,7 +211,7 @@ def training_object(workload, precision, dev, rank, n_ranks, use_dist, n=64, ste
             it[0] += 1
             return gan.step(lr, hr, update_d=(it[0] - 1) % 3 == 0)["g_loss"]      # config.py:21 discriminator_update_freq = 3
         name = (f"BASELINE.json configs[4]: GAN iteration (discriminator half-step every 3rd iteration + generator "
-                f"half-step), {n} images per GPU, fp32 tensors"
+                f"half-step), {n} images per GPU, {'bf16 generator' if precision == 'bf16' else 'fp32'} tensors"
                 + (", generator forward of the discriminator half-step reused by the generator half-step" if reuse_forward else ""))
         metric = "GAN iteration images/s"
 
@@ -249,13 +250,17 @@ def training_object(workload, precision, dev, rank, n_ranks, use_dist, n=64, ste
     classes = {k: {"ms_per_step": round(v[0] / 3, 3), "launches_per_step": round(v[1] / 3, 1), "share": round(v[0] / total, 3)}
                for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
     top, (top_ms, top_calls, top_work) = max(prof.items(), key=lambda kv: kv[1][0])
-    f16 = precision == "f16"
+    f16, b16 = precision == "f16", precision == "bf16"
     wpath = T.wgrad_path()
     if top.startswith("conv3x3"):
         split = (T.conv_path() if "forward" in top else wpath) == "split"
-        ratio, peak = ((1.0 if f16 else SPLIT_EXECUTED), PEAK["f16"]) if split else (WINO_EXECUTED, PEAK["f32"])
-        kname = ("c3s::conv3x3_f32s_kernel<*, TERMS=%d>" % (1 if f16 else 3) if "forward" in top
-                 else "wg1::conv3x3_wgrad_split_kernel<%d> + conv3x3_wgrad_reduce_kernel" % (1 if f16 else 3)) if split else top
+        ratio, peak = ((1.0 if (f16 or b16) else SPLIT_EXECUTED), PEAK["f16"]) if split else (WINO_EXECUTED, PEAK["f32"])
+        if b16:
+            kname = ("c3::conv3x3_bf16_kernel<*> (the eval forward's kernel, identity epilogue)" if "forward" in top
+                     else "wg1::conv3x3_wgrad_split_kernel<1, bf16 operands> + conv3x3_wgrad_reduce_kernel")
+        else:
+            kname = ("c3s::conv3x3_f32s_kernel<*, TERMS=%d>" % (1 if f16 else 3) if "forward" in top
+                     else "wg1::conv3x3_wgrad_split_kernel<%d> + conv3x3_wgrad_reduce_kernel" % (1 if f16 else 3)) if split else top
         ach = top_work * ratio / (top_ms * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": f"{kname} ({top}: {round(top_calls / 3)} launches per step, the class with the "
                                            f"largest share of the step's device time: {classes[top]['share']:.0%})",
@@ -273,15 +278,23 @@ def training_object(workload, precision, dev, rank, n_ranks, use_dist, n=64, ste
         "metric": metric, "value": round(n * n_ranks * steps / dt, 1), "unit": "images/s", "n_gpus": n_ranks,
         "steps": steps, "warmup": max(warmup, 3), "ms_per_step": round(dt / steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f16 products, f32 accumulation and tensors" if f16 else "f32", "data": "synthetic",
+        "dtype": ("bf16 tensors and products, f32 accumulation" if b16 else
+                  "f16 products, f32 accumulation and tensors" if f16 else "f32"), "data": "synthetic",
         "config": {"workload": name, "batch_per_gpu": n, "global_batch": n * n_ranks, "parallelism": f"dp{n_ranks}",
                    "conv_products": ("f16: the generator's 3x3 convs (forward, data and weight gradient) multiply operands "
                                      "rounded to f16 after power-of-two range scaling, ONE f16 MFMA per product -- the reference "
                                      "runs this step under bf16 autocast (train.py:91); tests/test_gpu_training.py shows the "
                                      "gradients closer to the reference's fp32 step than its own autocast step is") if f16
+                                    else ("bf16: activation and gradient tensors are bf16 in HBM, every conv multiplies bf16 "
+                                          "operands with fp32 accumulation, BatchNorm / PReLU / attention compute in fp32 and "
+                                          "round once when they store -- the storage and product types of the reference's own "
+                                          "step under torch.autocast(bfloat16) (train.py:91); tests/test_gpu_training_bf16.py: "
+                                          "as close to the reference's fp32 step as its own autocast step is") if b16
                                     else "fp32 accuracy: two-term f16 splits of both operands, THREE f16 MFMAs per product",
-                   "precision": f"fp32 tensors and accumulation; 3x3 conv kernels: {T.conv_path()} (forward, data gradient), "
-                                f"{wpath} (weight gradient); operands range-scaled by powers of two",
+                   "precision": ("bf16 tensors, fp32 accumulation, parameters / statistics / parameter gradients / images fp32"
+                                 if b16 else
+                                 f"fp32 tensors and accumulation; 3x3 conv kernels: {T.conv_path()} (forward, data gradient), "
+                                 f"{wpath} (weight gradient); operands range-scaled by powers of two"),
                    "collective": "one all-reduce of the flat gradient buffer per optimizer step (12.86 MB generator, "
                                  "23.5 MB discriminator)"},
         "loss_last": float(loss), "roofline": roof, "time_by_operator_class": classes, "cpu_baseline": cpu}
@@ -296,7 +309,7 @@ def main():
     ap.add_argument("--workload", choices=["cfg1", "cfg2", "cfg3", "cfg4"], default="cfg1",
                     help="which leg is the headline `value` (cfg3 / cfg4: the training steps, their own line)")
     ap.add_argument("--train-batch", type=int, default=64, help="images per GPU per training step (cfg3 / cfg4)")
-    ap.add_argument("--train-precision", choices=["fp32", "f16"], default="fp32",
+    ap.add_argument("--train-precision", choices=["fp32", "f16", "bf16"], default="fp32",
                     help="cfg3 / cfg4: products of the generator's 3x3 convs -- fp32 (three f16 MFMAs per product) or f16 "
                          "(operands rounded to f16, fp32 accumulation: what the reference's bf16 autocast does to its convs)")
     ap.add_argument("--gan-reuse-forward", action="store_true",
@@ -436,18 +449,21 @@ def main():
         algorithmic = TRUNK_CONV_FLOP_PER_IMAGE * args.batch / (ms_launch * 1e-3) / 1e12
         path, ratio, peak, kname, counts = f32_pricing(dt_name)
         executed = algorithmic * ratio
-        traffic = None
+        traffic = mfma_busy = None
         tpath = os.path.join(ROOT, "profiles", f"traffic_{dt_name}.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 if tj.get("path", "wino" if dt_name == "f32" else path) == path:      # a summary measured on another kernel says nothing here
                     traffic = tj.get("conv3x3_trunk_hbm_bytes_per_launch")
+                    mfma_busy = tj.get("mfma_busy_frac")
             except Exception:
-                traffic = None
+                traffic = mfma_busy = None
         return {"bound": "mfma", "kernel": f"{kname} (33 trunk launches)", "achieved": round(executed, 2),
                 "peak": peak, "unit": "TFLOP/s", "frac": round(executed / peak, 4),
                 "traffic": traffic, "ms_per_launch": ms_launch,
+                # SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles) from the same committed PMC summary as traffic
+                "mfma_busy_by_counter": mfma_busy,
                 "flop_per_launch_executed": int(TRUNK_CONV_FLOP_PER_IMAGE * args.batch * ratio),
                 "flop_per_launch_algorithmic": TRUNK_CONV_FLOP_PER_IMAGE * args.batch,
                 "algorithmic_tflops": round(algorithmic, 2), "counts": counts}
@@ -559,7 +575,7 @@ def main():
     if not args.no_training_legs:
         for wl in ("cfg3", "cfg4"):
             train_objs[wl] = {}
-            for prec in ("fp32", "f16"):
+            for prec in ("fp32", "f16", "bf16"):
                 o = training_object(wl, prec, dev, rank, n_ranks, use_dist, n=args.train_batch,
                                     steps=max(3, min(10, args.steps)), warmup=3, cpu=cpu_train.get(wl))
                 for k in ("higher_is_better", "scaling", "vs_baseline", "data", "n_gpus", "unit"):

@@ -325,6 +325,55 @@ SRGEN_API int srgen_pixel_loss_grad(const float* sr, const float* hr, int n, int
 SRGEN_API int srgen_adamw(float* p, const float* g, float* m, float* v, size_t numel, float lr, float beta1,
                           float beta2, float eps, float weight_decay, int step, void* stream);
 
+/* ---- 16-bit pre-train step: the operators above over bf16 activation and gradient tensors ---------------------------------
+ * Replaces: the same sites as the section above when the step runs as the reference runs it, inside
+ * torch.autocast(device_type="cuda", dtype=torch.bfloat16) (/root/reference/train.py:91,148,166): autocast keeps the
+ * conv / BatchNorm / PReLU outputs and their gradients in bf16 and multiplies bf16 operands with fp32 accumulation; so do
+ * these.  Every (n, h, w, 96) NHWC tensor argument typed `void*` is bf16; parameters, batch statistics, parameter
+ * gradients, the 3-channel input image and the output image (fp32 NCHW) are as in the fp32 entries; arithmetic inside a
+ * kernel is fp32 and a result is rounded once (to nearest even) when stored.  Shapes, scratch sizes and error behaviour as
+ * the fp32 entry of the same name.  Host mirror: superresolution_amd/training.py (`precision="bf16"`).
+ *   srgen_bf16_pack_many       weight images for srgen_conv3x3_nhwc_bf16 from the live fp32 OIHW weights, all of a step's
+ *                              in one launch: out[i] = 165,888 bytes per 96-channel cout block; mode / block as
+ *                              srgen_split_pack
+ *   srgen_conv3x3_nhwc_bf16    conv forward and data gradient (the eval forward's bf16 MFMA kernel with identity epilogue)
+ *   srgen_conv3x3_wgrad_bf16   weight + bias gradient from bf16 x and dy (v_mfma_f32_32x32x16_bf16), fp32 result
+ *   srgen_bn_train_fwd_bf16 / srgen_bn_train_bwd_bf16, srgen_prelu_scalar_fwd_bf16 / _bwd_bf16,
+ *   srgen_chan_attn_nhwc_bf16 / srgen_chan_attn_bwd_bf16: as their fp32 namesakes
+ *   srgen_conv9x9_c3_nhwc_split_bf16   fp32 3-channel image -> bf16 NHWC (stem forward, head data gradient)
+ *   srgen_conv9x9_c3_wgrad_bf16        bf16 activation x fp32 image -> fp32 weight gradient
+ *   srgen_head_nhwc_bf16       bf16 (n,128,128,96) -> fp32 (n,3,125,125); wpack: bf16 8-element units [ky 9][g 6][h 2][n 32],
+ *                              ci = 16 g + 8 h + e, n = 3 kx + co (27 of 32 used)
+ */
+SRGEN_API int srgen_bf16_pack_many(int count, const float* const* w_oihw, const int* cout_total, const int* mode,
+                                   const int* block, void* const* out, void* stream);
+SRGEN_API int srgen_conv3x3_nhwc_bf16(const void* x, const void* wpack, const float* bias, const void* res, void* out, int n,
+                                      int hw, int cout_blocks, int shuffle, void* stream);
+SRGEN_API int srgen_conv3x3_wgrad_bf16(const void* x, const void* dy, int n, int hw, float* dw, float* dbias, void* scratch,
+                                       size_t scratch_bytes, void* stream);
+SRGEN_API int srgen_bn_train_fwd_bf16(const void* c, void* out, const float* gamma, const float* beta, const float* slope,
+                                      const void* res, float res_factor, float* batch_stats, size_t npix, void* scratch,
+                                      size_t scratch_bytes, void* stream);
+SRGEN_API int srgen_bn_train_bwd_bf16(const void* c, const void* dout, const float* batch_stats, const float* gamma,
+                                      const float* beta, const float* slope, float dout_scale, void* dc, float* dgamma,
+                                      float* dbeta, float* dslope, size_t npix, void* scratch, size_t scratch_bytes,
+                                      void* stream);
+SRGEN_API int srgen_prelu_scalar_fwd_bf16(const void* x, const float* slope, void* y, size_t numel, void* stream);
+SRGEN_API int srgen_prelu_scalar_bwd_bf16(const void* x, const void* dy, const void* dy2, const float* slope, void* dx,
+                                          float* dslope, size_t numel, void* scratch, size_t scratch_bytes, void* stream);
+SRGEN_API int srgen_conv9x9_c3_nhwc_split_bf16(const float* img, const float* wm, const float* bias, void* out, int n, int ih,
+                                               int iw, int oh, int ow, int flip, void* wpack_scratch,
+                                               size_t wpack_scratch_bytes, void* stream);
+SRGEN_API int srgen_conv9x9_c3_wgrad_bf16(const void* act, const float* img, int n, int ah, int aw, int ih, int iw, int flip,
+                                          float* r, float* dbias, void* scratch, size_t scratch_bytes, void* stream);
+SRGEN_API int srgen_head_nhwc_bf16(const void* v, const void* wpack, const float* bias, float* y, int n, void* stream);
+SRGEN_API int srgen_chan_attn_nhwc_bf16(void* x, const float* w1, const float* b1, const float* w2, const float* b2,
+                                        float* pool_partial, float* scale, int n, void* stream);
+SRGEN_API int srgen_chan_attn_bwd_bf16(const void* x, const void* dy, const float* pool_partial, const float* scale, int n,
+                                       const float* w1, const float* b1, const float* w2, const float* b2, void* dx,
+                                       float* dw1, float* db1, float* dw2, float* db2, void* scratch, size_t scratch_bytes,
+                                       void* stream);
+
 /* ---- Discriminator + relativistic-average GAN loss (forward values) ------------------------
  * SURVEY.md 8(f) "next" row 3: the PatchGAN critic the reference's GAN phase evaluates on hr and on
  * generator output (train.py:145-176).  Same conventions as above; fp32 only.  These entry points

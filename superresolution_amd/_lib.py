@@ -111,6 +111,24 @@ def lib() -> ctypes.CDLL:
     L.srgen_chan_attn_nhwc.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, vp]
     L.srgen_chan_attn_bwd_scratch_bytes.argtypes = [i, ctypes.POINTER(sz)]
     L.srgen_chan_attn_bwd.argtypes = [vp, vp, vp, vp, i, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
+    # the 16-bit step (bf16 activation / gradient tensors)
+    L.srgen_bf16_pack_many.argtypes = L.srgen_split_pack_many.argtypes
+    L.srgen_conv3x3_nhwc_bf16.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, vp]
+    L.srgen_conv3x3_wgrad_bf16.argtypes = [vp, vp, i, i, vp, vp, vp, sz, vp]
+    L.srgen_bn_train_fwd_bf16.argtypes = L.srgen_bn_train_fwd.argtypes
+    L.srgen_bn_train_bwd_bf16.argtypes = [vp, vp, vp, vp, vp, vp, f, vp, vp, vp, vp, sz, vp, sz, vp]
+    L.srgen_prelu_scalar_fwd_bf16.argtypes = L.srgen_prelu_scalar_fwd.argtypes
+    L.srgen_prelu_scalar_bwd_bf16.argtypes = L.srgen_prelu_scalar_bwd.argtypes
+    L.srgen_conv9x9_c3_nhwc_split_bf16.argtypes = L.srgen_conv9x9_c3_nhwc_split.argtypes
+    L.srgen_conv9x9_c3_wgrad_bf16.argtypes = L.srgen_conv9x9_c3_wgrad.argtypes
+    L.srgen_head_nhwc_bf16.argtypes = L.srgen_head_nhwc.argtypes
+    L.srgen_chan_attn_nhwc_bf16.argtypes = L.srgen_chan_attn_nhwc.argtypes
+    L.srgen_chan_attn_bwd_bf16.argtypes = L.srgen_chan_attn_bwd.argtypes
+    for name in ("srgen_bf16_pack_many", "srgen_conv3x3_nhwc_bf16", "srgen_conv3x3_wgrad_bf16", "srgen_bn_train_fwd_bf16",
+                 "srgen_bn_train_bwd_bf16", "srgen_prelu_scalar_fwd_bf16", "srgen_prelu_scalar_bwd_bf16",
+                 "srgen_conv9x9_c3_nhwc_split_bf16", "srgen_conv9x9_c3_wgrad_bf16", "srgen_head_nhwc_bf16",
+                 "srgen_chan_attn_nhwc_bf16", "srgen_chan_attn_bwd_bf16"):
+        getattr(L, name).restype = i
     psz = ctypes.POINTER(sz)
     L.srdisc_pack.argtypes = [vp, i, i, i, vp, vp]
     L.srdisc_stem_nhwc.argtypes = [vp, vp, vp, vp, i, i, i, f, vp]

@@ -98,6 +98,42 @@ struct StemArgs {
     float* out_amax = nullptr;   // split stem only: [N] device floats, zero on entry: max |out| per image (atomic max)
 };
 
+// ---- storage types of the training operators' activation / gradient tensors ------------------------------------
+// float (the fp32 and f16-product steps) or bf16 (the 16-bit step: the reference's autocast dtype, train.py:91).  The
+// elementwise and reduction kernels are templates over the storage type and compute in fp32: a thread's unit is four
+// consecutive channels = one 16-byte (fp32) or 8-byte (bf16) access.
+struct bf16_t { unsigned short bits; };
+template <typename T> __device__ __forceinline__ void ld4(const T* p, float (&o)[4]);
+template <> __device__ __forceinline__ void ld4<float>(const float* p, float (&o)[4])
+{
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 v = *(const f4*)p;
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+}
+template <> __device__ __forceinline__ void ld4<bf16_t>(const bf16_t* p, float (&o)[4])
+{
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    const u2 v = *(const u2*)p;
+    o[0] = __builtin_bit_cast(float, v.x << 16); o[1] = __builtin_bit_cast(float, v.x & 0xffff0000u);
+    o[2] = __builtin_bit_cast(float, v.y << 16); o[3] = __builtin_bit_cast(float, v.y & 0xffff0000u);
+}
+template <typename T> __device__ __forceinline__ void st4(T* p, const float (&o)[4]);
+template <> __device__ __forceinline__ void st4<float>(float* p, const float (&o)[4])
+{
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    *(f4*)p = f4{o[0], o[1], o[2], o[3]};
+}
+template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, const float (&o)[4])
+{
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    const b2 lo = {(__bf16)o[0], (__bf16)o[1]}, hi = {(__bf16)o[2], (__bf16)o[3]};     // round to nearest even
+    *(u2*)p = u2{__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
+}
+template <typename T> __device__ __forceinline__ float ld1(const T* p);
+template <> __device__ __forceinline__ float ld1<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ld1<bf16_t>(const bf16_t* p) { return __builtin_bit_cast(float, (unsigned)p->bits << 16); }
+
 // ---- channel attention: pool finish + FC + sigmoid + in-place scale ---------------------
 struct ChanAttnArgs {
     void* x;               // (N,64,64,96) NHWC, scaled in place
@@ -123,6 +159,7 @@ struct HeadArgs {
     const float* bias;     // [3]
     int N;
     const float* in_amax = nullptr;   // split head only: [N] bounds of max |in| per image (as Conv3x3Args, per image)
+    int y_f32 = 0;                    // bf16 head only: 1 = y is fp32 (the 16-bit training step)
 };
 
 // fp32 kernels (srgen_kernels_f32.hip)
@@ -149,6 +186,7 @@ struct Stem9Args {
     const float* slope;
     int N, ih, iw, oh, ow;
     float* out_amax;
+    int out_bf16 = 0;      // 1: out is a bf16 tensor
 };
 hipError_t launch_conv9x9_c3_split(const Stem9Args& a, hipStream_t s);
 // weight image (kStemSplitHalfs halfs + kSplitTailBytes) from the tap matrix wm[243][96] on the device
@@ -245,6 +283,10 @@ size_t bn_scratch_bytes();
 hipError_t launch_bn_train(float* t, size_t npix, const float* gamma, const float* beta, const float* slope,
                            const float* res, float res_factor, void* scratch, float* batch_stats, hipStream_t s,
                            float* out = nullptr);
+// the same over bf16 tensors (t, res, out); statistics and arithmetic in fp32
+hipError_t launch_bn_train_bf16(void* t, size_t npix, const float* gamma, const float* beta, const float* slope,
+                                const void* res, float res_factor, void* scratch, float* batch_stats, hipStream_t s,
+                                void* out = nullptr);
 
 // ---- backward-pass operators of the pre-train step (srgen_train_kernels.hip) --------------------------------------
 // Winograd weight image formed on the device from OIHW fp32 weights: mode 0 forward (cout_total 96 or 384, the
@@ -257,6 +299,9 @@ constexpr int kSplitPackMaxJobs = 96;
 struct SplitPackJob { const float* w; void* out; int cout_total, mode, block, pad; };
 struct SplitPackJobs { SplitPackJob j[kSplitPackMaxJobs]; int count; };
 hipError_t launch_split_pack_many(const SplitPackJobs& jobs, hipStream_t s);
+// bf16 images of the 16-bit step (the eval bf16 conv kernel's layout), kConv3x3Bf16Bytes per cout block, same jobs
+constexpr size_t kConv3x3Bf16Bytes = (size_t)9 * 96 * 96 * 2;
+hipError_t launch_bf16_pack_many(const SplitPackJobs& jobs, hipStream_t s);
 // out[kAmaxSlots] = per-workgroup maxima of |x| (their maximum is max |x|)
 hipError_t launch_absmax(const float* x, size_t n, float* out, hipStream_t s);
 // out[i] = max |x[i]| per image (per_image floats each, a multiple of 4), zero_out[i] = 0
@@ -268,12 +313,14 @@ hipError_t launch_conv3x3_wgrad(const float* x, const float* dy, int n, int h, f
 // the same on the split arithmetic (srgen_wgrad_f32s.hip; h a multiple of 64); dy_amax: kAmaxSlots partial maxima of |dy|
 // or nullptr (dy of order 1); scratch of conv3x3_wgrad_scratch_bytes
 // terms: 3 (split products) or 1 (f16 products), as Conv3x3Args::terms
-hipError_t launch_conv3x3_wgrad_split(const float* x, const float* dy, int n, int h, const float* dy_amax, float* dw,
-                                      float* dbias, void* scratch, hipStream_t s, int terms = 3);
+// bf16: x and dy are bf16 tensors (terms = 1, no dy_amax), multiplied on the bf16 matrix instruction
+hipError_t launch_conv3x3_wgrad_split(const void* x, const void* dy, int n, int h, const float* dy_amax, float* dw,
+                                      float* dbias, void* scratch, hipStream_t s, int terms = 3, bool bf16 = false);
 constexpr int kWgradSplitMaxSlices = 168;         // slab = [slices][9][96][96] floats, then [slices][96] bias partials
 size_t conv3x3_wgrad_split_scratch_bytes(int n, int h);
-hipError_t launch_conv3x3_wgrad_split_partial(const float* x, const float* dy, int n, int h, const float* dy_amax,
-                                              float* slab, float* bias_slab, int* slices_out, hipStream_t s, int terms = 3);
+hipError_t launch_conv3x3_wgrad_split_partial(const void* x, const void* dy, int n, int h, const float* dy_amax,
+                                              float* slab, float* bias_slab, int* slices_out, hipStream_t s, int terms = 3,
+                                              bool bf16 = false);
 size_t bn_bwd_scratch_bytes();
 // c: saved conv output; dt: gradient of the BatchNorm(+PReLU) output (scaled by dscale); stats: {mean, biased var}
 hipError_t launch_bn_train_bwd(const float* c, const float* dt, const float* stats, const float* gamma, const float* beta,
@@ -292,6 +339,19 @@ hipError_t launch_conv9x9_c3(const float* img, const float* wm, const float* bia
 size_t conv9x9_c3_wgrad_scratch_bytes(int n, int ah);
 hipError_t launch_conv9x9_c3_wgrad(const float* act, const float* img, int n, int ah, int aw, int ih, int iw, int flip, float* r,
                                    float* dbias, void* scratch, hipStream_t s);
+// the same operators over bf16 activation / gradient tensors (the 16-bit training step); parameters, statistics and
+// parameter gradients stay fp32
+hipError_t launch_bn_train_bwd_bf16(const void* c, const void* dt, const float* stats, const float* gamma, const float* beta,
+                                    const float* slope, float dscale, void* dc, float* dgamma, float* dbeta, float* dslope,
+                                    size_t npix, void* scratch, hipStream_t s);
+hipError_t launch_prelu_scalar_fwd_bf16(const void* x, const float* slope, void* y, size_t numel, hipStream_t s);
+hipError_t launch_prelu_scalar_bwd_bf16(const void* x, const void* dy, const void* dy2, const float* slope, void* dx,
+                                        float* dslope, size_t numel, void* scratch, hipStream_t s);
+hipError_t launch_conv9x9_c3_wgrad_bf16(const void* act, const float* img, int n, int ah, int aw, int ih, int iw, int flip, float* r,
+                                        float* dbias, void* scratch, hipStream_t s);
+hipError_t launch_chan_attn_bwd_bf16(const void* x, const void* dy, const float* pool_partial, const float* scale, int n, int hw,
+                                     const float* w1, const float* b1, const float* w2, const float* b2, void* dx, float* dw1,
+                                     float* db1, float* dw2, float* db2, void* scratch, hipStream_t s);
 size_t chan_attn_bwd_scratch_bytes(int n);
 hipError_t launch_chan_attn_bwd(const float* x, const float* dy, const float* pool_partial, const float* scale, int n, int hw,
                                 const float* w1, const float* b1, const float* w2, const float* b2, float* dx, float* dw1, float* db1,
@@ -299,6 +359,7 @@ hipError_t launch_chan_attn_bwd(const float* x, const float* dy, const float* po
 hipError_t launch_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
                         float wd, int step, hipStream_t s);
 hipError_t launch_pool_partial(const float* t, int n, int hw, int parts, float* pool_partial, hipStream_t s);
+hipError_t launch_pool_partial_bf16(const void* t, int n, int hw, int parts, float* pool_partial, hipStream_t s);
 
 // ---- packed-weight geometry shared by the packers (host) and the kernels ---------------
 // fp32 3x3: float4 units  [cout_block][tap 9][ci4 24][co 96] -> 4 consecutive ci

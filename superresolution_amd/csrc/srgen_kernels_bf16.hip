@@ -242,6 +242,8 @@ constexpr int HB_TS = 29;
 constexpr int HB_LDS_BYTES = 4 * HB_COLS * HB_TS * 4;     // 59,392 >= 2*HB_PLANE = 49,152
 constexpr int HB_PIECES = HB_ROWS * HB_COLS * 2 / 256;    // 16-byte pieces per thread and chunk: 12
 
+// OUT_F32: y is an fp32 tensor (the 16-bit training step hands the image to the fp32 loss kernels)
+template <bool OUT_F32>
 __global__ __launch_bounds__(256, 2) void head_bf16_kernel(HeadArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -334,6 +336,7 @@ __global__ __launch_bounds__(256, 2) void head_bf16_kernel(HeadArgs a)
     const int y = y0 + w;
     if (y < kOut) {
         __bf16* yo = (__bf16*)a.y + (size_t)n * 3 * kOut * kOut;
+        float* yf = (float*)a.y + (size_t)n * 3 * kOut * kOut;
         for (int i = lane; i < 3 * kOut; i += 64) {
             const int co = i / kOut, x = i - co * kOut;
             float s = a.bias[co];
@@ -342,7 +345,8 @@ __global__ __launch_bounds__(256, 2) void head_bf16_kernel(HeadArgs a)
                 const int xs = x + kx - 4;                   // x' of this tap; outside the image T is zero
                 if ((unsigned)xs < (unsigned)HB_COLS) s += Tl[xs * HB_TS + kx * 3 + co];
             }
-            yo[((size_t)co * kOut + y) * kOut + x] = (__bf16)s;
+            if constexpr (OUT_F32) yf[((size_t)co * kOut + y) * kOut + x] = s;
+            else yo[((size_t)co * kOut + y) * kOut + x] = (__bf16)s;
         }
     }
 }
@@ -354,12 +358,16 @@ hipError_t launch_head_bf16(const HeadArgs& a, hipStream_t s)
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        e = hipFuncSetAttribute((const void*)head_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+        e = hipFuncSetAttribute((const void*)head_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                HB_LDS_BYTES);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)head_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 HB_LDS_BYTES);
         if (e != hipSuccess) return e;
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    hipLaunchKernelGGL(head_bf16_kernel, dim3((unsigned)(a.N * (kHR / 4))), dim3(256), HB_LDS_BYTES, s, a);
+    if (a.y_f32) hipLaunchKernelGGL(head_bf16_kernel<true>, dim3((unsigned)(a.N * (kHR / 4))), dim3(256), HB_LDS_BYTES, s, a);
+    else hipLaunchKernelGGL(head_bf16_kernel<false>, dim3((unsigned)(a.N * (kHR / 4))), dim3(256), HB_LDS_BYTES, s, a);
     return hipGetLastError();
 }
 

@@ -320,7 +320,8 @@ hipError_t metrics_static_scratch(float** ptr)
 // update), bn_apply (normalise in place + PReLU, or residual + factor * normalised).
 constexpr int BN_THREADS = 240;                // 10 pixel rows x 24 float4 channel groups
 
-__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ t, size_t npix, double* partial)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ t, size_t npix, double* partial)
 {
     __shared__ double red[10][2][96];
     const int tid = threadIdx.x;
@@ -331,19 +332,25 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
         float sx[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
         size_t p = p0 + row;
         for (; p + 30 < p1; p += 40) {                          // four loads in flight per thread
-            float4 v[4];
+            float v[4][4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(t + (p + 10 * u) * 96 + c4 * 4);
+            for (int u = 0; u < 4; ++u) ld4(t + (p + 10 * u) * 96 + c4 * 4, v[u]);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                sx[0] += v[u].x; sx[1] += v[u].y; sx[2] += v[u].z; sx[3] += v[u].w;
-                sq[0] += v[u].x * v[u].x; sq[1] += v[u].y * v[u].y; sq[2] += v[u].z * v[u].z; sq[3] += v[u].w * v[u].w;
-            }
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    sx[e] += v[u][e];
+                    sq[e] += v[u][e] * v[u][e];
+                }
         }
         for (; p < p1; p += 10) {
-            const float4 v = *reinterpret_cast<const float4*>(t + p * 96 + c4 * 4);
-            sx[0] += v.x; sx[1] += v.y; sx[2] += v.z; sx[3] += v.w;
-            sq[0] += v.x * v.x; sq[1] += v.y * v.y; sq[2] += v.z * v.z; sq[3] += v.w * v.w;
+            float v[4];
+            ld4(t + p * 96 + c4 * 4, v);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                sx[e] += v[e];
+                sq[e] += v[e] * v[e];
+            }
         }
         for (int e = 0; e < 4; ++e) {
             red[row][0][c4 * 4 + e] = (double)sx[e];
@@ -400,32 +407,36 @@ __global__ __launch_bounds__(768) void bn_final_kernel(const double* partial, in
     }
 }
 
-__global__ __launch_bounds__(256) void bn_apply_kernel(const float* t, float* out, const float* __restrict__ scale_shift,
-                                                       const float* __restrict__ slope, const float* __restrict__ res,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* t, T* out, const float* __restrict__ scale_shift,
+                                                       const float* __restrict__ slope, const T* __restrict__ res,
                                                        float res_factor, size_t n4)
 {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
         const int c = (int)(i % 24) * 4;
-        float4 v = *reinterpret_cast<const float4*>(t + i * 4);
+        float v[4];
+        ld4(t + i * 4, v);
         const float4 sc = *reinterpret_cast<const float4*>(scale_shift + c);
         const float4 sh = *reinterpret_cast<const float4*>(scale_shift + 96 + c);
-        v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+        v[0] = fmaf(v[0], sc.x, sh.x); v[1] = fmaf(v[1], sc.y, sh.y); v[2] = fmaf(v[2], sc.z, sh.z); v[3] = fmaf(v[3], sc.w, sh.w);
         if (slope) {                                             // PReLU(ch), Generator.py:36
             const float4 sl = *reinterpret_cast<const float4*>(slope + c);
-            v.x = v.x >= 0.f ? v.x : v.x * sl.x; v.y = v.y >= 0.f ? v.y : v.y * sl.y;
-            v.z = v.z >= 0.f ? v.z : v.z * sl.z; v.w = v.w >= 0.f ? v.w : v.w * sl.w;
+            v[0] = v[0] >= 0.f ? v[0] : v[0] * sl.x; v[1] = v[1] >= 0.f ? v[1] : v[1] * sl.y;
+            v[2] = v[2] >= 0.f ? v[2] : v[2] * sl.z; v[3] = v[3] >= 0.f ? v[3] : v[3] * sl.w;
         }
         if (res) {                                               // x + 0.1 * block(x) (:42) / x1 + mid(x2) (:78)
-            const float4 r = *reinterpret_cast<const float4*>(res + i * 4);
-            v.x = fmaf(res_factor, v.x, r.x); v.y = fmaf(res_factor, v.y, r.y);
-            v.z = fmaf(res_factor, v.z, r.z); v.w = fmaf(res_factor, v.w, r.w);
+            float r[4];
+            ld4(res + i * 4, r);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaf(res_factor, v[e], r[e]);
         }
-        *reinterpret_cast<float4*>(out + i * 4) = v;
+        st4(out + i * 4, v);
     }
 }
 
 // per-image channel sums in the pool_partial layout of the conv epilogue: [N][parts][96], part = hw/parts pixels
-__global__ __launch_bounds__(256) void pool_partial_kernel(const float* __restrict__ t, int hw, int parts,
+template <typename T>
+__global__ __launch_bounds__(256) void pool_partial_kernel(const T* __restrict__ t, int hw, int parts,
                                                            float* pool_partial)
 {
     __shared__ float red[10][96];
@@ -436,8 +447,9 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(const float* __restri
         const int c4 = tid % 24, row = tid / 24;
         float s[4] = {0.f, 0.f, 0.f, 0.f};
         for (int p = row; p < per; p += 10) {
-            const float4 v = *reinterpret_cast<const float4*>(t + (p0 + p) * 96 + c4 * 4);
-            s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+            float v[4];
+            ld4(t + (p0 + p) * 96 + c4 * 4, v);
+            s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
         }
         for (int e = 0; e < 4; ++e) red[row][c4 * 4 + e] = s[e];
     }
@@ -451,26 +463,47 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(const float* __restri
 
 size_t bn_scratch_bytes() { return (size_t)kBnBlocks * 192 * sizeof(double) + 2 * 96 * sizeof(float); }
 
-hipError_t launch_bn_train(float* t, size_t npix, const float* gamma, const float* beta, const float* slope,
-                           const float* res, float res_factor, void* scratch, float* batch_stats, hipStream_t s, float* out)
+template <typename T>
+static hipError_t bn_train_t(T* t, size_t npix, const float* gamma, const float* beta, const float* slope, const T* res,
+                             float res_factor, void* scratch, float* batch_stats, hipStream_t s, T* out)
 {
     if (!out) out = t;                                   // in place (the forward-values path)
     double* partial = static_cast<double*>(scratch);
     float* ss = reinterpret_cast<float*>(partial + (size_t)kBnBlocks * 192);
     const int nb = npix < (size_t)kBnBlocks * 10 ? (int)((npix + 9) / 10) : kBnBlocks;
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(nb), dim3(256), 0, s, t, npix, partial);
+    hipLaunchKernelGGL(bn_stats_kernel<T>, dim3(nb), dim3(256), 0, s, t, npix, partial);
     hipLaunchKernelGGL(bn_final_kernel, dim3(8), dim3(768), 0, s, partial, nb, (double)npix, gamma, beta, 1e-5f, ss,
                        batch_stats);
     const size_t n4 = npix * 24;
     const size_t want = (n4 + 255) / 256;
-    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)(want < 16384 ? want : 16384)), dim3(256), 0, s, t, out, ss, slope,
+    hipLaunchKernelGGL(bn_apply_kernel<T>, dim3((unsigned)(want < 16384 ? want : 16384)), dim3(256), 0, s, t, out, ss, slope,
                        res, res_factor, n4);
     return hipGetLastError();
 }
 
+hipError_t launch_bn_train(float* t, size_t npix, const float* gamma, const float* beta, const float* slope,
+                           const float* res, float res_factor, void* scratch, float* batch_stats, hipStream_t s, float* out)
+{
+    return bn_train_t<float>(t, npix, gamma, beta, slope, res, res_factor, scratch, batch_stats, s, out);
+}
+
+hipError_t launch_bn_train_bf16(void* t, size_t npix, const float* gamma, const float* beta, const float* slope,
+                                const void* res, float res_factor, void* scratch, float* batch_stats, hipStream_t s, void* out)
+{
+    return bn_train_t<bf16_t>((bf16_t*)t, npix, gamma, beta, slope, (const bf16_t*)res, res_factor, scratch, batch_stats, s,
+                              (bf16_t*)out);
+}
+
 hipError_t launch_pool_partial(const float* t, int n, int hw, int parts, float* pool_partial, hipStream_t s)
 {
-    hipLaunchKernelGGL(pool_partial_kernel, dim3((unsigned)(n * parts)), dim3(256), 0, s, t, hw, parts, pool_partial);
+    hipLaunchKernelGGL(pool_partial_kernel<float>, dim3((unsigned)(n * parts)), dim3(256), 0, s, t, hw, parts, pool_partial);
+    return hipGetLastError();
+}
+
+hipError_t launch_pool_partial_bf16(const void* t, int n, int hw, int parts, float* pool_partial, hipStream_t s)
+{
+    hipLaunchKernelGGL(pool_partial_kernel<bf16_t>, dim3((unsigned)(n * parts)), dim3(256), 0, s, (const bf16_t*)t, hw, parts,
+                       pool_partial);
     return hipGetLastError();
 }
 

@@ -32,6 +32,8 @@ constexpr int PLANE = ROWS * RS * 8;               // bytes of one (high | low) 
 constexpr int NVAL = 3 * ROWS * RS;                // input values of a tile: 2,736
 constexpr int PER_THREAD = (NVAL + 255) / 256;     // ... per thread: 11
 
+// OUT_BF16: the NHWC output is stored as bf16 (the 16-bit training step), 8-byte pieces
+template <bool OUT_BF16>
 __global__ __launch_bounds__(256, 2) void stem_f32s_kernel(Stem9Args a)
 {
     __shared__ __attribute__((aligned(16))) char lds[2 * PLANE];
@@ -123,7 +125,9 @@ __global__ __launch_bounds__(256, 2) void stem_f32s_kernel(Stem9Args a)
     }
 
     // ---- epilogue (registers only): scale back, bias, PReLU, 16-byte NHWC stores, per-image maximum -----------------------
-    float* out = a.out + (((size_t)n * a.oh + y0 + w) * a.ow + x0 + p) * kC + 4 * h;
+    const size_t out_off = (((size_t)n * a.oh + y0 + w) * a.ow + x0 + p) * kC + 4 * h;
+    float* out = a.out + out_off;
+    bf16_t* outb = (bf16_t*)a.out + out_off;
     float vmax = 0.f;
 #pragma unroll
     for (int nt = 0; nt < 3; ++nt)
@@ -141,7 +145,12 @@ __global__ __launch_bounds__(256, 2) void stem_f32s_kernel(Stem9Args a)
                     o[e] = t >= 0.f ? t : t * s4[e];
                     vmax = fmaxf(vmax, fabsf(o[e]));
                 }
-                *(f32x4*)(out + (size_t)(32 * mt) * kC + 32 * nt + 8 * G) = o;
+                if constexpr (OUT_BF16) {
+                    const float o4[4] = {o[0], o[1], o[2], o[3]};
+                    st4(outb + (size_t)(32 * mt) * kC + 32 * nt + 8 * G, o4);
+                } else {
+                    *(f32x4*)(out + (size_t)(32 * mt) * kC + 32 * nt + 8 * G) = o;
+                }
             }
         }
     if (a.out_amax) {                                 // non-negative floats order like their bit patterns
@@ -200,13 +209,14 @@ hipError_t launch_conv9x9_c3_split(const Stem9Args& a, hipStream_t s)
     if (a.N <= 0 || a.ih <= 0 || a.iw <= 0 || a.oh <= 0 || a.ow <= 0 || (a.oh & 3) || (a.ow & 63)) return hipErrorInvalidValue;
     const long long blocks = (long long)a.N * (a.oh >> 2) * (a.ow >> 6);
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(sfs::stem_f32s_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    if (a.out_bf16) hipLaunchKernelGGL(sfs::stem_f32s_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(sfs::stem_f32s_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
 hipError_t launch_stem_f32_split(const StemArgs& a, hipStream_t s)
 {
-    Stem9Args g{(const float*)a.x, (float*)a.out, a.wpack, a.bias, a.slope, a.N, kLR, kLR, kLR, kLR, a.out_amax};
+    Stem9Args g{(const float*)a.x, (float*)a.out, a.wpack, a.bias, a.slope, a.N, kLR, kLR, kLR, kLR, a.out_amax, 0};
     return launch_conv9x9_c3_split(g, s);
 }
 

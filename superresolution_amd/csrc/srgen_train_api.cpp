@@ -308,7 +308,7 @@ int srgen_conv9x9_c3_nhwc_split(const float* img, const float* wm, const float* 
     if (wpack_scratch_bytes < kStemSplitHalfs * 2 + kSplitTailBytes) return fail(SRGEN_E_WORKSPACE, "weight-image scratch too small");
     if (!aligned16(out) || !aligned16(bias) || !aligned16(wpack_scratch)) return fail(SRGEN_E_INVALID, "out / bias / scratch must be 16-byte aligned");
     HIP_TRY(launch_stem_split_pack(wm, flip ? 1 : 0, wpack_scratch, (hipStream_t)stream));
-    Stem9Args a{img, out, wpack_scratch, bias, nullptr, n, ih, iw, oh, ow, nullptr};
+    Stem9Args a{img, out, wpack_scratch, bias, nullptr, n, ih, iw, oh, ow, nullptr, 0};
     HIP_TRY(launch_conv9x9_c3_split(a, (hipStream_t)stream));
     return SRGEN_OK;
 }

@@ -218,6 +218,53 @@ hipError_t launch_split_pack(const float* w, void* out, int cout_total, int mode
     return hipGetLastError();
 }
 
+// ---- bf16 weight images of the 16-bit step (layout of srgen_conv3x3_bf16.hip: 8-element units [cb][tap][ci/8][co 96]),
+// from the live fp32 OIHW weights, many images in one launch; modes as split_pack_body ----
+__global__ __launch_bounds__(256) void bf16_pack_many_kernel(SplitPackJobs jobs)
+{
+    const SplitPackJob j = jobs.j[blockIdx.y];
+    const int cb = j.mode == 0 ? j.cout_total / 96 : 1;
+    const int shuffle = j.cout_total == 384;
+    const int idx = blockIdx.x * 256 + threadIdx.x;               // over (b, ci / 8, co): one 16-byte unit per tap
+    if (idx >= cb * 12 * 96) return;
+    const int co = idx % 96, c8 = (idx / 96) % 12, b = idx / (96 * 12);
+    const float* __restrict__ w = j.w;
+    for (int tap = 0; tap < 9; ++tap) {
+        unsigned u[4];
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) {
+            float v[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int ci = 8 * c8 + 2 * e2 + k;
+                if (j.mode == 0) {
+                    const int oc = shuffle ? 4 * co + b : 96 * b + co;
+                    v[k] = w[((size_t)oc * 96 + ci) * 9 + tap];
+                } else {
+                    const int oc = shuffle ? 4 * ci + j.block : 96 * j.block + ci;
+                    v[k] = w[((size_t)oc * 96 + co) * 9 + (8 - tap)];
+                }
+            }
+            typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+            const b2 t = {(__bf16)v[0], (__bf16)v[1]};
+            u[e2] = __builtin_bit_cast(unsigned, t);
+        }
+        typedef unsigned u4 __attribute__((ext_vector_type(4)));
+        *(u4*)((char*)j.out + ((((size_t)b * 9 + tap) * 12 + c8) * 96 + co) * 16) = u4{u[0], u[1], u[2], u[3]};
+    }
+}
+
+hipError_t launch_bf16_pack_many(const SplitPackJobs& jobs, hipStream_t s)
+{
+    if (jobs.count <= 0 || jobs.count > kSplitPackMaxJobs) return hipErrorInvalidValue;
+    int max_cb = 1;
+    for (int i = 0; i < jobs.count; ++i)
+        if (jobs.j[i].mode == 0 && jobs.j[i].cout_total / 96 > max_cb) max_cb = jobs.j[i].cout_total / 96;
+    hipLaunchKernelGGL(bf16_pack_many_kernel, dim3((unsigned)((max_cb * 12 * 96 + 255) / 256), (unsigned)jobs.count), dim3(256), 0,
+                       s, jobs);
+    return hipGetLastError();
+}
+
 // ---- conv3x3 weight gradient ------------------------------------------------------------------------------
 // dW[co][ci][ky][kx] = sum over pixels dY[n][y][x][co] * X[n][y+ky-1][x+kx-1][ci] (zero outside the image).
 // A GEMM with M = co, N = ci, K = pixels per tap.  Workgroup = (tap, slice of image rows), 3 waves, wave w owning
@@ -687,14 +734,14 @@ size_t conv3x3_wgrad_scratch_bytes(int n, int h)
     return m > split ? m : split;
 }
 
-hipError_t launch_conv3x3_wgrad_split(const float* x, const float* dy, int n, int h, const float* dy_amax, float* dw,
-                                      float* dbias, void* scratch, hipStream_t s, int terms)
+hipError_t launch_conv3x3_wgrad_split(const void* x, const void* dy, int n, int h, const float* dy_amax, float* dw,
+                                      float* dbias, void* scratch, hipStream_t s, int terms, bool bf16)
 {
     int slices = 0;
     float* slab = (float*)scratch;
     // (the bias partials sit behind the largest slab the slice count can ask for)
     float* bias_slab = slab + (size_t)kWgradSplitMaxSlices * 9 * 9216;
-    hipError_t e = launch_conv3x3_wgrad_split_partial(x, dy, n, h, dy_amax, slab, bias_slab, &slices, s, terms);
+    hipError_t e = launch_conv3x3_wgrad_split_partial(x, dy, n, h, dy_amax, slab, bias_slab, &slices, s, terms, bf16);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3(9 * 9216 / 64), dim3(1024), 0, s, slab, bias_slab, slices, dw, dbias);
     return hipGetLastError();
@@ -750,7 +797,8 @@ __device__ __forceinline__ void bn_consts(const float* stats, const float* gamma
     q = beta[ch] - stats[ch] * p;
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* __restrict__ c, const float* __restrict__ dt,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const T* __restrict__ c, const T* __restrict__ dt,
                                                            const float* __restrict__ stats, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ slope,
                                                            float dscale, size_t npix, double* partial)
@@ -768,13 +816,14 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* __restri
         const size_t per = (npix + gridDim.x - 1) / gridDim.x;
         const size_t p0 = (size_t)blockIdx.x * per, p1 = p0 + per < npix ? p0 + per : npix;
         float s_dz[4] = {0, 0, 0, 0}, s_dzx[4] = {0, 0, 0, 0}, s_sl[4] = {0, 0, 0, 0};
-        const float* cp = c + (p0 + row) * 96 + c4 * 4;
-        const float* dp = dt + (p0 + row) * 96 + c4 * 4;
+        const T* cp = c + (p0 + row) * 96 + c4 * 4;
+        const T* dp = dt + (p0 + row) * 96 + c4 * 4;
         const int iters = p1 > p0 + row ? (int)((p1 - p0 - row + 9) / 10) : 0;     // pixels of this thread
         int it = 0;
         for (; it + 4 <= iters; it += 4) {
-            f32x4 cv0 = *(const f32x4*)(cp), cv1 = *(const f32x4*)(cp + 960), cv2 = *(const f32x4*)(cp + 1920), cv3 = *(const f32x4*)(cp + 2880);
-            f32x4 dv0 = *(const f32x4*)(dp), dv1 = *(const f32x4*)(dp + 960), dv2 = *(const f32x4*)(dp + 1920), dv3 = *(const f32x4*)(dp + 2880);
+            float cv0[4], cv1[4], cv2[4], cv3[4], dv0[4], dv1[4], dv2[4], dv3[4];
+            ld4(cp, cv0); ld4(cp + 960, cv1); ld4(cp + 1920, cv2); ld4(cp + 2880, cv3);
+            ld4(dp, dv0); ld4(dp + 960, dv1); ld4(dp + 1920, dv2); ld4(dp + 2880, dv3);
             cp += 3840; dp += 3840;
 #define BNB_ADD(cv, dv)                                                     \
             _Pragma("unroll") for (int e = 0; e < 4; ++e) {                 \
@@ -790,8 +839,9 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* __restri
             BNB_ADD(cv0, dv0) BNB_ADD(cv1, dv1) BNB_ADD(cv2, dv2) BNB_ADD(cv3, dv3)
         }
         for (; it < iters; ++it) {
-            const f32x4 cv = *(const f32x4*)(cp);
-            const f32x4 dv = *(const f32x4*)(dp);
+            float cv[4], dv[4];
+            ld4(cp, cv);
+            ld4(dp, dv);
             cp += 960; dp += 960;
             BNB_ADD(cv, dv)
         }
@@ -860,9 +910,10 @@ __global__ __launch_bounds__(1024) void bn_bwd_final_kernel(const double* partia
 }
 
 // grid * 256 is a multiple of 24, so a thread meets the same four channels at every stride: constants in registers
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ c, const float* __restrict__ dt,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ c, const T* __restrict__ dt,
                                                            const float* __restrict__ slope, const float* __restrict__ coef,
-                                                           float dscale, float* __restrict__ dc, size_t n4, float* amax)
+                                                           float dscale, T* __restrict__ dc, size_t n4, float* amax)
 {
     const size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x;
     float m = 0.f;
@@ -875,9 +926,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         S[e] = slope ? slope[ch + e] : 1.f;
     }
     for (size_t i = i0; i < n4; i += (size_t)gridDim.x * 256) {
-        const f32x4 cv = *(const f32x4*)(c + i * 4);
-        const f32x4 dv = *(const f32x4*)(dt + i * 4);
-        f32x4 o;
+        float cv[4], dv[4], o[4];
+        ld4(c + i * 4, cv);
+        ld4(dt + i * 4, dv);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float z = fmaf(cv[e], P[e], Q[e]);
@@ -885,7 +936,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
             o[e] = fmaf(A[e], dz, -C[e]) - B[e] * cv[e];
             m = fmaxf(m, fabsf(o[e]));
         }
-        *(f32x4*)(dc + i * 4) = o;
+        st4(dc + i * 4, o);
     }
     // max |dc| for the split-f16 data-gradient conv that reads dc next (its in_amax): slot = workgroup mod kAmaxSlots,
     // zeroed by bn_bwd_final_kernel; non-negative floats order like their bit patterns
@@ -897,23 +948,39 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 
 size_t bn_bwd_scratch_bytes() { return (size_t)BNB_BLOCKS * 288 * sizeof(double) + 480 * sizeof(float); }
 
-hipError_t launch_bn_train_bwd(const float* c, const float* dt, const float* stats, const float* gamma, const float* beta,
-                               const float* slope, float dscale, float* dc, float* dgamma, float* dbeta, float* dslope,
-                               size_t npix, void* scratch, hipStream_t s, float* dc_amax)
+template <typename T>
+static hipError_t bn_train_bwd_t(const T* c, const T* dt, const float* stats, const float* gamma, const float* beta,
+                                 const float* slope, float dscale, T* dc, float* dgamma, float* dbeta, float* dslope,
+                                 size_t npix, void* scratch, hipStream_t s, float* dc_amax)
 {
     static_assert(kAmaxSlots == 1024, "bn_bwd_final_kernel zeroes one slot per thread");
     double* partial = (double*)scratch;
     float* coef = (float*)(partial + (size_t)BNB_BLOCKS * 288);
     const int nb = npix < (size_t)BNB_BLOCKS * 10 ? (int)((npix + 9) / 10) : BNB_BLOCKS;
-    hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(nb), dim3(256), 0, s, c, dt, stats, gamma, beta, slope, dscale, npix, partial);
+    hipLaunchKernelGGL(bn_bwd_stats_kernel<T>, dim3(nb), dim3(256), 0, s, c, dt, stats, gamma, beta, slope, dscale, npix, partial);
     hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(8), dim3(1024), 0, s, partial, nb, (double)npix, stats, gamma, beta, coef, dgamma,
                        dbeta, dslope, dc_amax);
     const size_t n4 = npix * 24;
     size_t want = (n4 + 255) / 256;
     if (want > 6144) want = 6144;
     want = (want + 2) / 3 * 3;                                   // (grid * 256) % 24 == 0
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)want), dim3(256), 0, s, c, dt, slope, coef, dscale, dc, n4, dc_amax);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3((unsigned)want), dim3(256), 0, s, c, dt, slope, coef, dscale, dc, n4, dc_amax);
     return hipGetLastError();
+}
+
+hipError_t launch_bn_train_bwd(const float* c, const float* dt, const float* stats, const float* gamma, const float* beta,
+                               const float* slope, float dscale, float* dc, float* dgamma, float* dbeta, float* dslope,
+                               size_t npix, void* scratch, hipStream_t s, float* dc_amax)
+{
+    return bn_train_bwd_t<float>(c, dt, stats, gamma, beta, slope, dscale, dc, dgamma, dbeta, dslope, npix, scratch, s, dc_amax);
+}
+
+hipError_t launch_bn_train_bwd_bf16(const void* c, const void* dt, const float* stats, const float* gamma, const float* beta,
+                                    const float* slope, float dscale, void* dc, float* dgamma, float* dbeta, float* dslope,
+                                    size_t npix, void* scratch, hipStream_t s)
+{
+    return bn_train_bwd_t<bf16_t>((const bf16_t*)c, (const bf16_t*)dt, stats, gamma, beta, slope, dscale, (bf16_t*)dc, dgamma,
+                                  dbeta, dslope, npix, scratch, s, nullptr);
 }
 
 // ---- gradient of the pixel losses: weighted_l1(sr, hr) + w_ssim * (1 - ssim(sr, hr)) with respect to sr -------------
@@ -1094,35 +1161,44 @@ hipError_t launch_adamw(float* p, const float* g, float* m, float* v, size_t n, 
 
 
 // ---- scalar-slope PReLU (Generator.py:51, 9, 70), elementwise over any fp32 tensor -----------------------------------
-__global__ __launch_bounds__(256) void prelu_scalar_fwd_kernel(const float* __restrict__ x, const float* __restrict__ slope,
-                                                               float* __restrict__ y, size_t n4)
+template <typename T>
+__global__ __launch_bounds__(256) void prelu_scalar_fwd_kernel(const T* __restrict__ x, const float* __restrict__ slope,
+                                                               T* __restrict__ y, size_t n4)
 {
     const float a = slope[0];
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-        f32x4 v = *(const f32x4*)(x + i * 4);
+        float v[4];
+        ld4(x + i * 4, v);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.f ? v[e] : v[e] * a;
-        *(f32x4*)(y + i * 4) = v;
+        st4(y + i * 4, v);
     }
 }
 
 // dx = dy * (x >= 0 ? 1 : a), dy = dy1 (+ dy2: a second consumer of the PReLU output, e.g. the long skip);
 // per-workgroup partial of da = sum dy * x * [x < 0] (fp64 across threads)
-__global__ __launch_bounds__(256) void prelu_scalar_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                               const float* __restrict__ dy2, const float* __restrict__ slope,
-                                                               float* __restrict__ dx, size_t n4, double* __restrict__ partial)
+template <typename T>
+__global__ __launch_bounds__(256) void prelu_scalar_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                               const T* __restrict__ dy2, const float* __restrict__ slope,
+                                                               T* __restrict__ dx, size_t n4, double* __restrict__ partial)
 {
     __shared__ double red[256];
     const float a = slope[0];
     float acc = 0.f;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-        const f32x4 v = *(const f32x4*)(x + i * 4);
-        f32x4 d = *(const f32x4*)(dy + i * 4);
-        if (dy2) d += *(const f32x4*)(dy2 + i * 4);
+        float v[4], d[4];
+        ld4(x + i * 4, v);
+        ld4(dy + i * 4, d);
+        if (dy2) {
+            float d2[4];
+            ld4(dy2 + i * 4, d2);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[e] += d2[e];
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e)
             if (v[e] < 0.f) { acc += d[e] * v[e]; d[e] *= a; }
-        *(f32x4*)(dx + i * 4) = d;
+        st4(dx + i * 4, d);
     }
     red[threadIdx.x] = (double)acc;
     __syncthreads();
@@ -1150,24 +1226,48 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restr
 constexpr int PRELU_BLOCKS = 2048;
 size_t prelu_scratch_bytes() { return PRELU_BLOCKS * sizeof(double); }
 
-hipError_t launch_prelu_scalar_fwd(const float* x, const float* slope, float* y, size_t numel, hipStream_t s)
+template <typename T>
+static hipError_t prelu_fwd_t(const T* x, const float* slope, T* y, size_t numel, hipStream_t s)
 {
     const size_t n4 = numel / 4;
     size_t nb = (n4 + 255) / 256;
     if (nb > 16384) nb = 16384;
-    hipLaunchKernelGGL(prelu_scalar_fwd_kernel, dim3((unsigned)nb), dim3(256), 0, s, x, slope, y, n4);
+    hipLaunchKernelGGL(prelu_scalar_fwd_kernel<T>, dim3((unsigned)nb), dim3(256), 0, s, x, slope, y, n4);
     return hipGetLastError();
+}
+
+template <typename T>
+static hipError_t prelu_bwd_t(const T* x, const T* dy, const T* dy2, const float* slope, T* dx, float* dslope, size_t numel,
+                              void* scratch, hipStream_t s)
+{
+    const size_t n4 = numel / 4;
+    size_t nb = (n4 + 255) / 256;
+    if (nb > PRELU_BLOCKS) nb = PRELU_BLOCKS;
+    hipLaunchKernelGGL(prelu_scalar_bwd_kernel<T>, dim3((unsigned)nb), dim3(256), 0, s, x, dy, dy2, slope, dx, n4, (double*)scratch);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, (const double*)scratch, (int)nb, dslope);
+    return hipGetLastError();
+}
+
+hipError_t launch_prelu_scalar_fwd(const float* x, const float* slope, float* y, size_t numel, hipStream_t s)
+{
+    return prelu_fwd_t<float>(x, slope, y, numel, s);
 }
 
 hipError_t launch_prelu_scalar_bwd(const float* x, const float* dy, const float* dy2, const float* slope, float* dx, float* dslope,
                                    size_t numel, void* scratch, hipStream_t s)
 {
-    const size_t n4 = numel / 4;
-    size_t nb = (n4 + 255) / 256;
-    if (nb > PRELU_BLOCKS) nb = PRELU_BLOCKS;
-    hipLaunchKernelGGL(prelu_scalar_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, s, x, dy, dy2, slope, dx, n4, (double*)scratch);
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, (const double*)scratch, (int)nb, dslope);
-    return hipGetLastError();
+    return prelu_bwd_t<float>(x, dy, dy2, slope, dx, dslope, numel, scratch, s);
+}
+
+hipError_t launch_prelu_scalar_fwd_bf16(const void* x, const float* slope, void* y, size_t numel, hipStream_t s)
+{
+    return prelu_fwd_t<bf16_t>((const bf16_t*)x, slope, (bf16_t*)y, numel, s);
+}
+
+hipError_t launch_prelu_scalar_bwd_bf16(const void* x, const void* dy, const void* dy2, const float* slope, void* dx,
+                                        float* dslope, size_t numel, void* scratch, hipStream_t s)
+{
+    return prelu_bwd_t<bf16_t>((const bf16_t*)x, (const bf16_t*)dy, (const bf16_t*)dy2, slope, (bf16_t*)dx, dslope, numel, scratch, s);
 }
 
 // ---- 9x9 convs against a 3-channel NCHW image (stem Generator.py:50; head Generator.py:71 transposed) -------------------
@@ -1255,7 +1355,8 @@ hipError_t launch_conv9x9_c3(const float* img, const float* wm, const float* bia
 }
 
 // slab [slice][96][256]; wave wv owns taps j in [64 wv, 64 wv + 64) x all 96 channels
-__global__ __launch_bounds__(256) void conv9x9_c3_wgrad_kernel(const float* __restrict__ act, const float* __restrict__ img,
+template <typename T>
+__global__ __launch_bounds__(256) void conv9x9_c3_wgrad_kernel(const T* __restrict__ act, const float* __restrict__ img,
                                                                int total_rows, int ah, int aw, int ih, int iw, int flip,
                                                                int rows_per_slice, float* __restrict__ slab,
                                                                float* __restrict__ bias_slab)
@@ -1285,13 +1386,13 @@ __global__ __launch_bounds__(256) void conv9x9_c3_wgrad_kernel(const float* __re
     const int r0 = slice * rows_per_slice, r1 = min(r0 + rows_per_slice, total_rows);
     for (int row = r0; row < r1; ++row) {
         const int n = row / ah, y = row - n * ah;
-        const float* ar = act + (size_t)row * aw * 96 + col;
+        const T* ar = act + (size_t)row * aw * 96 + col;
         const float* ibase = img + (size_t)n * 3 * ih * iw + (size_t)y * iw;
         for (int x0 = 0; x0 < aw; x0 += 4) {
             const int x = x0 + kq;
             float av[6], bv[4];
 #pragma unroll
-            for (int a = 0; a < 6; ++a) av[a] = ar[(size_t)x * 96 + 16 * a];                    // A[i = channel][k = pixel]
+            for (int a = 0; a < 6; ++a) av[a] = ld1(ar + (size_t)x * 96 + 16 * a);               // A[i = channel][k = pixel]
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const bool ok = tv[t] && (unsigned)(y + tdy[t]) < (unsigned)ih && (unsigned)(x + tdx[t]) < (unsigned)iw;
@@ -1367,26 +1468,40 @@ size_t conv9x9_c3_wgrad_scratch_bytes(int n, int ah)
     return ((size_t)slices * 96 * 256 + (size_t)slices * 96) * sizeof(float);
 }
 
-hipError_t launch_conv9x9_c3_wgrad(const float* act, const float* img, int n, int ah, int aw, int ih, int iw, int flip, float* r,
-                                   float* dbias, void* scratch, hipStream_t s)
+template <typename T>
+static hipError_t conv9x9_c3_wgrad_t(const T* act, const float* img, int n, int ah, int aw, int ih, int iw, int flip, float* r,
+                                     float* dbias, void* scratch, hipStream_t s)
 {
     const int total_rows = n * ah;
     const int slices = wgrad9_slices(total_rows);
     const int rps = (total_rows + slices - 1) / slices;
     float* slab = (float*)scratch;
     float* bias_slab = slab + (size_t)slices * 96 * 256;
-    hipLaunchKernelGGL(conv9x9_c3_wgrad_kernel, dim3((unsigned)slices), dim3(256), 0, s, act, img, total_rows, ah, aw, ih, iw, flip,
+    hipLaunchKernelGGL(conv9x9_c3_wgrad_kernel<T>, dim3((unsigned)slices), dim3(256), 0, s, act, img, total_rows, ah, aw, ih, iw, flip,
                        rps, slab, bias_slab);
     hipLaunchKernelGGL(conv9x9_c3_wgrad_reduce_kernel, dim3(96 * 256 / 64), dim3(1024), 0, s, slab, bias_slab, slices, r,
                        dbias);
     return hipGetLastError();
 }
 
+hipError_t launch_conv9x9_c3_wgrad(const float* act, const float* img, int n, int ah, int aw, int ih, int iw, int flip, float* r,
+                                   float* dbias, void* scratch, hipStream_t s)
+{
+    return conv9x9_c3_wgrad_t<float>(act, img, n, ah, aw, ih, iw, flip, r, dbias, scratch, s);
+}
+
+hipError_t launch_conv9x9_c3_wgrad_bf16(const void* act, const float* img, int n, int ah, int aw, int ih, int iw, int flip, float* r,
+                                        float* dbias, void* scratch, hipStream_t s)
+{
+    return conv9x9_c3_wgrad_t<bf16_t>((const bf16_t*)act, img, n, ah, aw, ih, iw, flip, r, dbias, scratch, s);
+}
+
 // ---- ChannelAttention backward (Generator.py:15-27): y = x * s[n][c], s = sigmoid(W2 relu(W1 mean_hw(x) + b1) + b2) ------
 // pass 1: ds[n][c] = sum_hw dy * x (per image, fixed order); pass 2 (one workgroup): the two tiny FC layers backward over
 // all images (weight / bias gradients summed over the batch in image order) and dpool[n][c]; pass 3:
 // dx = dy * s + dpool / hw.
-__global__ __launch_bounds__(256) void ca_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy, int hw,
+template <typename T>
+__global__ __launch_bounds__(256) void ca_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy, int hw,
                                                             int parts, float* __restrict__ ds_partial)
 {
     __shared__ float red[10][96];
@@ -1397,8 +1512,9 @@ __global__ __launch_bounds__(256) void ca_bwd_reduce_kernel(const float* __restr
         const int c4 = tid % 24, row = tid / 24;
         float s[4] = {0.f, 0.f, 0.f, 0.f};
         for (int p = row; p < per; p += 10) {
-            const f32x4 v = *(const f32x4*)(x + (p0 + p) * 96 + c4 * 4);
-            const f32x4 d = *(const f32x4*)(dy + (p0 + p) * 96 + c4 * 4);
+            float v[4], d[4];
+            ld4(x + (p0 + p) * 96 + c4 * 4, v);
+            ld4(dy + (p0 + p) * 96 + c4 * 4, d);
 #pragma unroll
             for (int e = 0; e < 4; ++e) s[e] += v[e] * d[e];
         }
@@ -1479,38 +1595,56 @@ __global__ __launch_bounds__(256) void ca_bwd_wgrad_kernel(const float* __restri
     }
 }
 
-__global__ __launch_bounds__(256) void ca_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ scale,
-                                                           const float* __restrict__ dpool, int hw, float* __restrict__ dx, size_t n4)
+template <typename T>
+__global__ __launch_bounds__(256) void ca_bwd_apply_kernel(const T* __restrict__ dy, const float* __restrict__ scale,
+                                                           const float* __restrict__ dpool, int hw, T* __restrict__ dx, size_t n4)
 {
     const float inv = 1.f / (float)hw;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
         const int c = (int)(i % 24) * 4;
         const size_t img = i / ((size_t)hw * 24);
-        f32x4 d = *(const f32x4*)(dy + i * 4);
+        float d[4];
+        ld4(dy + i * 4, d);
         const f32x4 sc = *(const f32x4*)(scale + img * 96 + c);
         const f32x4 dp = *(const f32x4*)(dpool + img * 96 + c);
 #pragma unroll
         for (int e = 0; e < 4; ++e) d[e] = fmaf(d[e], sc[e], dp[e] * inv);
-        *(f32x4*)(dx + i * 4) = d;
+        st4(dx + i * 4, d);
     }
 }
 
-hipError_t launch_chan_attn_bwd(const float* x, const float* dy, const float* pool_partial, const float* scale, int n, int hw,
-                                const float* w1, const float* b1, const float* w2, const float* b2, float* dx, float* dw1, float* db1,
-                                float* dw2, float* db2, void* scratch, hipStream_t s)
+template <typename T>
+static hipError_t chan_attn_bwd_t(const T* x, const T* dy, const float* pool_partial, const float* scale, int n, int hw,
+                                  const float* w1, const float* b1, const float* w2, const float* b2, T* dx, float* dw1, float* db1,
+                                  float* dw2, float* db2, void* scratch, hipStream_t s)
 {
     constexpr int parts = 16;
     float* ds_partial = (float*)scratch;                          // [n][16][96]
     float* dpool = ds_partial + (size_t)n * parts * 96;           // [n][96]
-    hipLaunchKernelGGL(ca_bwd_reduce_kernel, dim3((unsigned)(n * parts)), dim3(256), 0, s, x, dy, hw, parts, ds_partial);
+    hipLaunchKernelGGL(ca_bwd_reduce_kernel<T>, dim3((unsigned)(n * parts)), dim3(256), 0, s, x, dy, hw, parts, ds_partial);
     float* vec = dpool + (size_t)n * 96;                          // [n][216]
     hipLaunchKernelGGL(ca_bwd_fc_kernel, dim3((unsigned)n), dim3(128), 0, s, pool_partial, ds_partial, parts, hw, w1, b1, w2, scale,
                        dpool, vec);
     hipLaunchKernelGGL(ca_bwd_wgrad_kernel, dim3(5), dim3(256), 0, s, vec, n, dw1, db1, dw2, db2);
     const size_t n4 = (size_t)n * hw * 24;
     const size_t want = (n4 + 255) / 256;
-    hipLaunchKernelGGL(ca_bwd_apply_kernel, dim3((unsigned)(want < 16384 ? want : 16384)), dim3(256), 0, s, dy, scale, dpool, hw, dx, n4);
+    hipLaunchKernelGGL(ca_bwd_apply_kernel<T>, dim3((unsigned)(want < 16384 ? want : 16384)), dim3(256), 0, s, dy, scale, dpool, hw, dx, n4);
     return hipGetLastError();
+}
+
+hipError_t launch_chan_attn_bwd(const float* x, const float* dy, const float* pool_partial, const float* scale, int n, int hw,
+                                const float* w1, const float* b1, const float* w2, const float* b2, float* dx, float* dw1, float* db1,
+                                float* dw2, float* db2, void* scratch, hipStream_t s)
+{
+    return chan_attn_bwd_t<float>(x, dy, pool_partial, scale, n, hw, w1, b1, w2, b2, dx, dw1, db1, dw2, db2, scratch, s);
+}
+
+hipError_t launch_chan_attn_bwd_bf16(const void* x, const void* dy, const float* pool_partial, const float* scale, int n, int hw,
+                                     const float* w1, const float* b1, const float* w2, const float* b2, void* dx, float* dw1,
+                                     float* db1, float* dw2, float* db2, void* scratch, hipStream_t s)
+{
+    return chan_attn_bwd_t<bf16_t>((const bf16_t*)x, (const bf16_t*)dy, pool_partial, scale, n, hw, w1, b1, w2, b2, (bf16_t*)dx,
+                                   dw1, db1, dw2, db2, scratch, s);
 }
 
 size_t chan_attn_bwd_scratch_bytes(int n) { return ((size_t)n * 16 * 96 + (size_t)n * 96 + (size_t)n * 216) * sizeof(float); }

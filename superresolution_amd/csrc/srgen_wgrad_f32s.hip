@@ -36,6 +36,7 @@
 #include "srgen_internal.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace srgen {
 namespace wgs {
@@ -45,8 +46,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef short s4v __attribute__((__vector_size__(8)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 #define MFMA_H(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+#define MFMA_B(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, (a)), __builtin_bit_cast(bf8, (b)), (c), 0, 0, 0)
 
 constexpr int DY_PITCH = 192, X_PITCH = 64, X_ROWS = 66;
 static_assert(kAmaxSlots == 4 * 256, "one float4 of partial maxima per thread");
@@ -77,12 +81,19 @@ template <int TERMS> struct Lds {
 };
 static_assert(192 * 4 * 4 <= Lds<1>::BYTES, "bias reduction fits");
 
-template <int TERMS>
-__global__ __launch_bounds__(256, TERMS == 3 ? 1 : 2) void conv3x3_wgrad_split_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+// BF: x and dy are bf16 tensors (the 16-bit step): staged as they are (8-byte pieces, no conversion, no scaling), multiplied
+// on v_mfma_f32_32x32x16_bf16; TERMS = 1 only
+template <int TERMS, bool BF = false>
+__global__ __launch_bounds__(256, TERMS == 3 ? 1 : 2) void conv3x3_wgrad_split_kernel(const void* __restrict__ x_, const void* __restrict__ dy_,
                                                                    int total_rows, int H, int W, int rows_per_slice,
                                                                    const float* __restrict__ dy_amax,
                                                                    float* __restrict__ slab, float* __restrict__ bias_slab)
 {
+    static_assert(!BF || TERMS == 1, "bf16 operands: one product term");
+    using Piece = std::conditional_t<BF, u32x2, f32x4>;          // four consecutive channels
+    constexpr int ES = BF ? 2 : 4;                                // bytes per element
+    const char* const x = (const char*)x_;
+    const char* const dy = (const char*)dy_;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int DY_BYTES = Lds<TERMS>::DY_BYTES, X_BYTES = Lds<TERMS>::X_BYTES, XR = Lds<TERMS>::XR, XZ = Lds<TERMS>::XZ;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -124,51 +135,67 @@ __global__ __launch_bounds__(256, TERMS == 3 ? 1 : 2) void conv3x3_wgrad_split_k
 
     // ---- staging: waves 0-2 the dY row segment of unit (row, seg), wave 3 X row row + 1 (the row that unit's
     // successor is the first to need), eight / nine 16-byte pieces per thread ----
-    f32x4 st0[9];
+    Piece st0[9];
     // one piece -> its f16 record; TERMS = 3: high part by truncation (11 significant bits) at rec, the rest, rounded, in the
     // low image `lo_off` behind it; TERMS = 1: rounded to nearest
-    auto store_h4 = [&](f32x4 v, char* rec, int lo_off) {
-        h4 r, l;
+    auto store_h4 = [&](Piece pv, char* rec, int lo_off) {
+        if constexpr (BF) {
+            *(u32x2*)rec = pv;                        // four bf16 channels as they are
+        } else {
+            const f32x4 v = pv;
+            h4 r, l;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if (TERMS == 3) {
-                const float hi = __uint_as_float(__float_as_uint(v[e]) & 0xFFFFE000u);
-                r[e] = (_Float16)hi;
-                l[e] = (_Float16)(v[e] - hi);
-            } else {
-                r[e] = (_Float16)v[e];
+            for (int e = 0; e < 4; ++e) {
+                if (TERMS == 3) {
+                    const float hi = __uint_as_float(__float_as_uint(v[e]) & 0xFFFFE000u);
+                    r[e] = (_Float16)hi;
+                    l[e] = (_Float16)(v[e] - hi);
+                } else {
+                    r[e] = (_Float16)v[e];
+                }
             }
+            *(h4*)rec = r;
+            if (TERMS == 3) *(h4*)(rec + lo_off) = l;
         }
-        *(h4*)rec = r;
-        if (TERMS == 3) *(h4*)(rec + lo_off) = l;
+    };
+    auto piece_f32 = [&](Piece pv) -> f32x4 {
+        if constexpr (BF)
+            return f32x4{__uint_as_float(pv.x << 16), __uint_as_float(pv.x & 0xffff0000u), __uint_as_float(pv.y << 16),
+                         __uint_as_float(pv.y & 0xffff0000u)};
+        else
+            return pv;
+    };
+    auto piece_scaled = [&](Piece pv) -> Piece {      // dY times 2^kd (fp32 tensors only)
+        if constexpr (BF) return pv;
+        else return pv * in_mul;
     };
     // (no branches below the wave level in here: the unit's MFMAs, fragment reads and splits are one basic block)
     const float bias_mul = do_bias ? 1.f : 0.f;
 #define WG1_STAGE_OPS(LOAD, CONVERT, ARR)                                                                                 \
     auto LOAD = [&](int row, int seg) {                                                                                   \
         if (is_dy) {                                                                                                      \
-            const float* src = dy + ((size_t)min(row, total_rows - 1) * W + seg * 64) * 96 + sp0 * 96 + 4 * sq;           \
-            _Pragma("unroll") for (int it = 0; it < 8; ++it) ARR[it] = *(const f32x4*)(src + it * 8 * 96);                 \
+            const char* src = dy + (((size_t)min(row, total_rows - 1) * W + seg * 64) * 96 + sp0 * 96 + 4 * sq) * ES;     \
+            _Pragma("unroll") for (int it = 0; it < 8; ++it) ARR[it] = *(const Piece*)(src + (size_t)it * 8 * 96 * ES);   \
         } else {                          /* any row: clamped into the tensor (a row nobody multiplies) */                \
             const int rr = min(max(row + 1, 0), total_rows - 1);                                                          \
-            const float* src = x + (size_t)rr * W * 96 + 32 * ct + 4 * sq;                                                \
+            const char* src = x + ((size_t)rr * W * 96 + 32 * ct + 4 * sq) * ES;                                          \
             _Pragma("unroll") for (int it = 0; it < 9; ++it) {                                                            \
                 const int xx = min(max(seg * 64 + sp0 + 8 * it - 1, 0), W - 1);                                           \
-                ARR[it] = *(const f32x4*)(src + (size_t)xx * 96);                                                         \
+                ARR[it] = *(const Piece*)(src + (size_t)xx * 96 * ES);                                                    \
             }                                                                                                             \
         }                                                                                                                 \
     };                                                                                                                    \
     /* piece `it` (< 8) of dY unit (row, seg) -> dY buffer b */                                                           \
     auto CONVERT##_dy = [&](int it, int b, float bm) {      /* bm: 1 where this unit counts for the bias sums, else 0 */  \
-        bsum += ARR[it] * bm;                                                                                             \
-        store_h4(ARR[it] * in_mul, lds + b * DY_BYTES + (sp0 + 8 * it) * DY_PITCH + sq * 8, DY_HALF);                     \
+        bsum += piece_f32(ARR[it]) * bm;                                                                                  \
+        store_h4(piece_scaled(ARR[it]), lds + b * DY_BYTES + (sp0 + 8 * it) * DY_PITCH + sq * 8, DY_HALF);                \
     };                                                                                                                    \
     /* piece `it` (< 9) of X row row + 1 -> its ring slot (halo pixels 66 .. 71 are written and never read) */            \
     auto CONVERT##_x = [&](int it, int row, int seg) {                                                                    \
         const int r = sp0 + 8 * it;                                                                                       \
         const int xx = seg * 64 + r - 1;                                                                                  \
         const bool ok = (it != 0 && it != 8) || (unsigned)xx < (unsigned)W;     /* only halo pixels 0, 65 can be outside */ \
-        store_h4(ok ? ARR[it] : f32x4{0.f, 0.f, 0.f, 0.f}, lds + XR + ((row + 1) & 3) * X_BYTES + r * X_PITCH + sq * 8, X_HALF); \
+        store_h4(ok ? ARR[it] : Piece{}, lds + XR + ((row + 1) & 3) * X_BYTES + r * X_PITCH + sq * 8, X_HALF);            \
     }
     WG1_STAGE_OPS(load0, convert0, st0);
 #undef WG1_STAGE_OPS
@@ -213,7 +240,8 @@ __global__ __launch_bounds__(256, TERMS == 3 ? 1 : 2) void conv3x3_wgrad_split_k
                         acc[kx][c] = MFMA_H(al, bh[kx], acc[kx][c]);
                         acc[kx][c] = MFMA_H(ah, bl[kx], acc[kx][c]);
                     }
-                    acc[kx][c] = MFMA_H(ah, bh[kx], acc[kx][c]);
+                    if constexpr (BF) acc[kx][c] = MFMA_B(ah, bh[kx], acc[kx][c]);
+                    else acc[kx][c] = MFMA_H(ah, bh[kx], acc[kx][c]);
                 }
             }
             cv(2 * ks, b ^ 1, bm);                    // a quarter of the next unit's dY under these MFMAs
@@ -302,11 +330,11 @@ size_t conv3x3_wgrad_split_scratch_bytes(int n, int h)
     return ((size_t)kWgradSplitMaxSlices * 9 * 9216 + (size_t)kWgradSplitMaxSlices * 96) * sizeof(float);     // the largest slice count
 }
 
-hipError_t launch_conv3x3_wgrad_split_partial(const float* x, const float* dy, int n, int h, const float* dy_amax,
-                                              float* slab, float* bias_slab, int* slices_out, hipStream_t s, int terms)
+hipError_t launch_conv3x3_wgrad_split_partial(const void* x, const void* dy, int n, int h, const float* dy_amax,
+                                              float* slab, float* bias_slab, int* slices_out, hipStream_t s, int terms, bool bf16)
 {
     using namespace wg1;
-    if (n <= 0 || h <= 0 || (h & 63) || (terms != 1 && terms != 3)) return hipErrorInvalidValue;
+    if (n <= 0 || h <= 0 || (h & 63) || (terms != 1 && terms != 3) || (bf16 && terms != 1)) return hipErrorInvalidValue;
     const int total_rows = n * h;
     static bool attr_set[64] = {};
     int dev = 0;
@@ -319,7 +347,10 @@ hipError_t launch_conv3x3_wgrad_split_partial(const float* x, const float* dy, i
     }
     const int slices = conv3x3_wgrad_split_slices(total_rows, terms);
     const int rps = (total_rows + slices - 1) / slices;
-    if (terms == 1)
+    if (bf16)
+        hipLaunchKernelGGL((conv3x3_wgrad_split_kernel<1, true>), dim3((unsigned)(slices * 3)), dim3(256), Lds<1>::BYTES, s, x, dy,
+                           total_rows, h, h, rps, (const float*)nullptr, slab, bias_slab);
+    else if (terms == 1)
         hipLaunchKernelGGL(conv3x3_wgrad_split_kernel<1>, dim3((unsigned)(slices * 3)), dim3(256), Lds<1>::BYTES, s, x, dy,
                            total_rows, h, h, rps, dy_amax, slab, bias_slab);
     else

@@ -204,7 +204,7 @@ class Generator(nn.Module):
         xc, code, dt = self._prepare(x)
         if xc.shape[0] == 0:
             raise ValueError("Expected more than 1 value per channel when training, got an empty batch")
-        if self.train_precision not in ("auto", "fp32", "f16"):
+        if self.train_precision not in ("auto", "fp32", "f16", "bf16"):
             raise RuntimeError(f"train_precision '{self.train_precision}': expected auto, fp32 or f16")
         precision = T.resolve_precision(self.train_precision)
         if self.train_precision == "auto" and code != _lib.SRGEN_F32 and T.conv_path() == "split":

@@ -23,6 +23,7 @@ from . import _lib
 WINO_FLOATS = 16 * 96 * 96           # Winograd weight image of one 96 -> 96 conv
 SPLIT_HALFS = 2 * 9 * 96 * 96         # split-f16 weight image of one 96 -> 96 conv: (hi, lo) per weight
 AMAX_SLOTS = 1024                     # SRGEN_AMAX_SLOTS (include/srgen.h)
+BF16_IMAGE_ELEMS = 9 * 96 * 96        # bf16 weight image of one 96 -> 96 conv (the eval forward's bf16 kernel)
 SPLIT_TAIL_HALFS = 64                 # ... and its 128-byte tail: 32 partial maxima of |w| (the weights' scale)
 STEM_SPLIT_BYTES = 9 * 3 * 3 * 2 * 64 * 16 + 128     # split-f16 weight image of a 9x9 conv against a 3-channel image
 
@@ -80,14 +81,20 @@ def _conv_flops(x, wpack, bias=None, res=None, cout_blocks=1, **k):
 
 
 def _bytes_of(n_tensors):
-    return lambda c, *a, **k: float(n_tensors * c.numel() * 4)
+    return lambda c, *a, **k: float(n_tensors * c.numel() * c.element_size())
 
 
-def _chk_nhwc(name: str, t: torch.Tensor) -> None:
-    if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous() or t.dim() != 4 or t.shape[3] != 96 \
-            or t.shape[1] != t.shape[2]:
-        raise RuntimeError(f"{name}: expected a contiguous fp32 ROCm tensor (n, hw, hw, 96), got {tuple(t.shape)} "
-                           f"{t.dtype} on {t.device}; there is no CPU fallback")
+def _chk_nhwc(name: str, t: torch.Tensor, like: Optional[torch.Tensor] = None) -> None:
+    if not t.is_cuda or t.dtype not in (torch.float32, torch.bfloat16) or not t.is_contiguous() or t.dim() != 4 \
+            or t.shape[3] != 96 or t.shape[1] != t.shape[2]:
+        raise RuntimeError(f"{name}: expected a contiguous fp32 (or, in the 16-bit step, bf16) ROCm tensor (n, hw, hw, 96), got "
+                           f"{tuple(t.shape)} {t.dtype} on {t.device}; there is no CPU fallback")
+    if like is not None and t.dtype != like.dtype:
+        raise RuntimeError(f"{name} is {t.dtype} beside a {like.dtype} operand: the operators do not mix storage types")
+
+
+def _bf(t: torch.Tensor) -> bool:
+    return t.dtype == torch.bfloat16
 
 
 class Workspace:
@@ -157,16 +164,20 @@ def wgrad_path() -> str:
 #         generator call (train.py:91-92,148-149,166-167), where every conv runs on 16-bit operands.  f16 keeps 11
 #         significant bits against bf16's 8, so this mode sits between the reference's autocast step and its fp32 step
 #         (tests/test_gpu_training.py: closer to the fp32 gradients than the reference's own autocast gradients are).
+# "bf16": the 16-bit step -- activations and gradients are bf16 TENSORS (half the bytes of every BatchNorm / PReLU pass, no
+#         conversion in the convs' staging), bf16 MFMA products, fp32 accumulation: the storage and product types of the
+#         reference's autocast step itself.  Parameters, statistics, parameter gradients and the images stay fp32.
 _CONV_PRECISION = ["fp32"]
 
 
 @contextlib.contextmanager
 def conv_precision(precision: str):
-    """Within the block ``conv3x3`` / ``conv3x3_wgrad`` run at ``precision`` ("fp32" | "f16"; split path only)."""
-    if precision not in ("fp32", "f16"):
-        raise RuntimeError(f"conv precision '{precision}': expected fp32 or f16")
-    if precision == "f16" and conv_path() != "split":
-        raise RuntimeError("f16 conv products exist on the split path only (SRGEN_F32_CONV3X3 unset or 'split')")
+    """Within the block ``conv3x3`` / ``conv3x3_wgrad`` run at ``precision`` ("fp32" | "f16" | "bf16"; the 16-bit ones on the
+    split path only), and ``GeneratorGrad.forward`` keeps its activations in fp32 ("fp32", "f16") or bf16 ("bf16")."""
+    if precision not in ("fp32", "f16", "bf16"):
+        raise RuntimeError(f"conv precision '{precision}': expected fp32, f16 or bf16")
+    if precision != "fp32" and conv_path() != "split":
+        raise RuntimeError("16-bit conv products exist on the split path only (SRGEN_F32_CONV3X3 unset or 'split')")
     old = _CONV_PRECISION[0]
     _CONV_PRECISION[0] = precision
     try:
@@ -215,6 +226,35 @@ def split_pack_many(jobs) -> list:
     return outs
 
 
+def bf16_pack_many(jobs) -> list:
+    """Weight images of the bf16 3x3 kernel for a list of ``(weight, mode, block)`` in one launch
+    (``srgen_bf16_pack_many``), as views of one bf16 buffer."""
+    ws = []
+    for w, mode, block in jobs:
+        if not w.is_cuda or w.dtype != torch.float32 or w.dim() != 4 or tuple(w.shape[1:]) != (96, 3, 3):
+            raise RuntimeError(f"expected a ROCm fp32 (cout, 96, 3, 3) weight, got {tuple(w.shape)} on {w.device}")
+        ws.append(w.detach().contiguous())
+    dev = ws[0].device
+    sizes = [(w.shape[0] // 96 if mode == 0 else 1) * BF16_IMAGE_ELEMS for w, (_, mode, _) in zip(ws, jobs)]
+    buf = torch.empty(sum(sizes), dtype=torch.bfloat16, device=dev)
+    outs, off = [], 0
+    for n in sizes:
+        outs.append(buf[off:off + n])
+        off += n
+    done = 0
+    with torch.cuda.device(dev):
+        while done < len(jobs):
+            k = min(96, len(jobs) - done)
+            sl = slice(done, done + k)
+            vp, ci = ctypes.c_void_p, ctypes.c_int
+            _lib.check(_lib.lib().srgen_bf16_pack_many(
+                k, (vp * k)(*[w.data_ptr() for w in ws[sl]]), (ci * k)(*[w.shape[0] for w in ws[sl]]),
+                (ci * k)(*[m for _, m, _ in jobs[sl]]), (ci * k)(*[b for _, _, b in jobs[sl]]),
+                (vp * k)(*[o.data_ptr() for o in outs[sl]]), _stream(ws[0])))
+            done += k
+    return outs
+
+
 # Weight images made ahead of a step: inside ``packed_weights(jobs)`` ``conv_pack`` serves the images of the listed (weight,
 # mode, block) from ONE batched pack (two launches instead of two per image: 146 launches of ~5 us in a pre-train step).
 # The weights must not change inside the block (they do not: the optimizer steps after the backward).
@@ -229,7 +269,7 @@ def packed_weights(jobs, outs=None):
         yield None
         return
     if outs is None:
-        outs = split_pack_many(jobs)
+        outs = bf16_pack_many(jobs) if _CONV_PRECISION[0] == "bf16" else split_pack_many(jobs)
     old = dict(_PACKED)
     for (w, mode, block), o in zip(jobs, outs):
         _PACKED[(w.data_ptr(), mode, block)] = o
@@ -246,6 +286,8 @@ def conv_pack(w: torch.Tensor, mode: int = 0, block: int = 0) -> torch.Tensor:
     hit = _PACKED.get((w.data_ptr(), mode, block))
     if hit is not None:
         return hit
+    if _CONV_PRECISION[0] == "bf16":
+        return bf16_pack_many([(w, mode, block)])[0]
     return split_pack(w, mode, block) if conv_path() == "split" else wino_pack(w, mode, block)
 
 
@@ -270,6 +312,19 @@ def conv3x3(x: torch.Tensor, wpack: torch.Tensor, bias: Optional[torch.Tensor] =
     _chk_nhwc("x", x)
     n, hw = x.shape[0], x.shape[1]
     oh = 2 * hw if shuffle else hw
+    if wpack.dtype == torch.bfloat16:                              # the 16-bit step: bf16 tensors, the eval forward's bf16 kernel
+        if not _bf(x) or (res is not None and not _bf(res)):
+            raise RuntimeError("a bf16 weight image multiplies bf16 tensors (conv_precision('bf16'))")
+        if wpack.numel() != cout_blocks * BF16_IMAGE_ELEMS or not wpack.is_contiguous():
+            raise RuntimeError(f"weight image of {wpack.numel()} bf16 values does not fit {cout_blocks} cout block(s)")
+        out = torch.empty((n, oh, oh, 96), dtype=torch.bfloat16, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().srgen_conv3x3_nhwc_bf16(x.data_ptr(), wpack.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                                          res.data_ptr() if res is not None else None, out.data_ptr(), n, hw,
+                                                          cout_blocks, 1 if shuffle else 0, _stream(x)))
+        return out
+    if _bf(x):
+        raise RuntimeError("a bf16 tensor needs a bf16 weight image (conv_precision('bf16'))")
     split = wpack.dtype == torch.float16
     want = cout_blocks * SPLIT_HALFS + SPLIT_TAIL_HALFS if split else cout_blocks * WINO_FLOATS
     if wpack.numel() != want or not wpack.is_contiguous():
@@ -351,7 +406,7 @@ def _conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, ws: Workspace, dw: Optiona
     """(dw (96, 96, 3, 3), dbias (96,)) of ``F.conv2d(x, w, b, padding=1)`` given ``dy``; NHWC fp32 operands.  ``dw`` /
     ``db``: write into these (``p.grad`` views) instead of fresh tensors."""
     _chk_nhwc("x", x)
-    _chk_nhwc("dy", dy)
+    _chk_nhwc("dy", dy, x)
     n, hw = x.shape[0], x.shape[1]
     L = _lib.lib()
     need = ctypes.c_size_t()
@@ -360,7 +415,10 @@ def _conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, ws: Workspace, dw: Optiona
     dw = _out(dw, (96, 96, 3, 3), x.device)
     db = _out(db, (96,), x.device)
     with torch.cuda.device(x.device):
-        if wgrad_path() == "split" and hw % 64 == 0:
+        if _bf(x):
+            _lib.check(L.srgen_conv3x3_wgrad_bf16(x.data_ptr(), dy.data_ptr(), n, hw, dw.data_ptr(), db.data_ptr(),
+                                                  scratch.data_ptr(), scratch.numel(), _stream(x)))
+        elif wgrad_path() == "split" and hw % 64 == 0:
             # the split kernel scales the gradient into f16's range: its producer's partial maxima, or a pass of our own
             amax = getattr(dy, "amax_slots", None)
             if amax is None:
@@ -388,8 +446,11 @@ def bn_train_fwd(c: torch.Tensor, gamma, beta, ws: Workspace, slope=None, res=No
     stats = torch.empty((2, 96), dtype=torch.float32, device=c.device)
     scratch = _bn_scratch(ws)
     npix = c.numel() // 96
+    if res is not None:
+        _chk_nhwc("res", res, c)
+    op = _lib.lib().srgen_bn_train_fwd_bf16 if _bf(c) else _lib.lib().srgen_bn_train_fwd
     with torch.cuda.device(c.device):
-        _lib.check(_lib.lib().srgen_bn_train_fwd(c.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+        _lib.check(op(c.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                                                  slope.data_ptr() if slope is not None else None,
                                                  res.data_ptr() if res is not None else None, float(res_factor),
                                                  stats.data_ptr(), npix, scratch.data_ptr(), scratch.numel(), _stream(c)))
@@ -402,7 +463,7 @@ def bn_train_bwd(c, dout, stats, gamma, beta, ws: Workspace, slope=None, dout_sc
     """(dc, dgamma, dbeta, dslope | None) of ``PReLU(bn(c))`` in train mode given ``dout * dout_scale``.  ``dgamma`` /
     ``dbeta`` / ``dslope``: write into these (``p.grad`` views) instead of fresh tensors."""
     _chk_nhwc("c", c)
-    _chk_nhwc("dout", dout)
+    _chk_nhwc("dout", dout, c)
     dev = c.device
     dc = torch.empty_like(c)
     dgamma, dbeta = _out(dgamma, (96,), dev), _out(dbeta, (96,), dev)
@@ -410,8 +471,15 @@ def bn_train_bwd(c, dout, stats, gamma, beta, ws: Workspace, slope=None, dout_sc
     scratch = _bn_scratch(ws)
     # the split-f16 data-gradient conv that reads dc next wants a bound of |dc| (conv3x3: scale_input): the apply kernel
     # leaves its partial maxima here, carried on the tensor as ``dc.amax_slots``
-    amax = torch.empty(AMAX_SLOTS, dtype=torch.float32, device=dev) if conv_path() == "split" else None
+    amax = torch.empty(AMAX_SLOTS, dtype=torch.float32, device=dev) if conv_path() == "split" and not _bf(c) else None
     with torch.cuda.device(dev):
+        if _bf(c):
+            _lib.check(_lib.lib().srgen_bn_train_bwd_bf16(c.data_ptr(), dout.data_ptr(), stats.data_ptr(), gamma.data_ptr(),
+                                                          beta.data_ptr(), slope.data_ptr() if slope is not None else None,
+                                                          float(dout_scale), dc.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                                          dslope.data_ptr() if dslope is not None else None, c.numel() // 96,
+                                                          scratch.data_ptr(), scratch.numel(), _stream(c)))
+            return dc, dgamma, dbeta, dslope
         _lib.check(_lib.lib().srgen_bn_train_bwd(c.data_ptr(), dout.data_ptr(), stats.data_ptr(), gamma.data_ptr(),
                                                  beta.data_ptr(), slope.data_ptr() if slope is not None else None,
                                                  float(dout_scale), dc.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
@@ -593,8 +661,9 @@ def resblock_backward(dout: torch.Tensor, saved: dict, block: torch.nn.Module, w
 def prelu_scalar(x: torch.Tensor, slope: torch.Tensor) -> torch.Tensor:
     """``nn.PReLU()`` with one slope (Generator.py:51, 9, 70), out of place (the pre-activation is kept for the backward)."""
     y = torch.empty_like(x)
+    op = _lib.lib().srgen_prelu_scalar_fwd_bf16 if _bf(x) else _lib.lib().srgen_prelu_scalar_fwd
     with torch.cuda.device(x.device):
-        _lib.check(_lib.lib().srgen_prelu_scalar_fwd(x.data_ptr(), slope.data_ptr(), y.data_ptr(), x.numel(), _stream(x)))
+        _lib.check(op(x.data_ptr(), slope.data_ptr(), y.data_ptr(), x.numel(), _stream(x)))
     return y
 
 
@@ -606,22 +675,34 @@ def prelu_scalar_bwd(x, dy, slope, ws: Workspace, dy2=None):
     scratch = ws.get("prelu", need.value)
     dx = torch.empty_like(x)
     dslope = torch.empty(1, dtype=torch.float32, device=x.device)
+    if dy.dtype != x.dtype or (dy2 is not None and dy2.dtype != x.dtype):
+        raise RuntimeError("prelu_scalar_bwd: operands of one storage type")
+    op = _lib.lib().srgen_prelu_scalar_bwd_bf16 if _bf(x) else _lib.lib().srgen_prelu_scalar_bwd
     with torch.cuda.device(x.device):
-        _lib.check(_lib.lib().srgen_prelu_scalar_bwd(x.data_ptr(), dy.data_ptr(), dy2.data_ptr() if dy2 is not None else None,
+        _lib.check(op(x.data_ptr(), dy.data_ptr(), dy2.data_ptr() if dy2 is not None else None,
                                                      slope.data_ptr(), dx.data_ptr(), dslope.data_ptr(), x.numel(),
                                                      scratch.data_ptr(), scratch.numel(), _stream(x)))
     return dx, dslope
 
 
 @_timed("9x9 stem / head")
-def conv9x9_c3(img: torch.Tensor, wm: torch.Tensor, bias, out_hw: int, flip: bool) -> torch.Tensor:
-    """out (n, out_hw, out_hw, 96) NHWC = bias + sum over the 243 taps of a 3-channel NCHW image times ``wm`` [243][96]."""
+def conv9x9_c3(img: torch.Tensor, wm: torch.Tensor, bias, out_hw: int, flip: bool,
+               out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """out (n, out_hw, out_hw, 96) NHWC = bias + sum over the 243 taps of a 3-channel NCHW image times ``wm`` [243][96].
+    ``out_dtype`` bfloat16 (the 16-bit step): the same fp32-accurate sums, rounded once when stored."""
     n, c, ih, iw = img.shape
     assert c == 3 and img.is_contiguous() and wm.shape == (243, 96) and wm.is_contiguous()
-    out = torch.empty((n, out_hw, out_hw, 96), dtype=torch.float32, device=img.device)
+    out = torch.empty((n, out_hw, out_hw, 96), dtype=out_dtype, device=img.device)
     pb = bias.data_ptr() if bias is not None else None
     with torch.cuda.device(img.device):
-        if conv_path() == "split" and out_hw % 64 == 0:
+        if out_dtype == torch.bfloat16:
+            if conv_path() != "split" or out_hw % 64:
+                raise RuntimeError("the bf16-output 9x9 conv exists on the split path, for outputs that are multiples of 64")
+            pack = torch.empty(STEM_SPLIT_BYTES, dtype=torch.uint8, device=img.device)
+            _lib.check(_lib.lib().srgen_conv9x9_c3_nhwc_split_bf16(img.data_ptr(), wm.data_ptr(), pb, out.data_ptr(), n, ih, iw,
+                                                                   out_hw, out_hw, 1 if flip else 0, pack.data_ptr(), pack.numel(),
+                                                                   _stream(img)))
+        elif conv_path() == "split" and out_hw % 64 == 0:
             # the eval stem's kernel (three f16 MFMAs per product, the input tile scaled by its own maximum, so gradients
             # of any magnitude keep fp32 accuracy); its weight image is made from wm on the device
             pack = torch.empty(STEM_SPLIT_BYTES, dtype=torch.uint8, device=img.device)
@@ -646,8 +727,9 @@ def conv9x9_c3_wgrad(act: torch.Tensor, img: torch.Tensor, ws: Workspace, flip: 
     scratch = ws.get("wgrad9", need.value)
     r = torch.empty((96, 243), dtype=torch.float32, device=act.device)
     db = torch.empty(96, dtype=torch.float32, device=act.device) if want_bias else None
+    op = L.srgen_conv9x9_c3_wgrad_bf16 if _bf(act) else L.srgen_conv9x9_c3_wgrad
     with torch.cuda.device(act.device):
-        _lib.check(L.srgen_conv9x9_c3_wgrad(act.data_ptr(), img.data_ptr(), n, ah, ah, ih, iw, 1 if flip else 0, r.data_ptr(),
+        _lib.check(op(act.data_ptr(), img.data_ptr(), n, ah, ah, ih, iw, 1 if flip else 0, r.data_ptr(),
                                             db.data_ptr() if db is not None else None, scratch.data_ptr(), scratch.numel(),
                                             _stream(act)))
     return r, db
@@ -684,12 +766,27 @@ def head_pack_split(w: torch.Tensor) -> torch.Tensor:
     return torch.cat([img.reshape(-1), tail.view(torch.float16)])
 
 
+def head_pack_bf16(w: torch.Tensor) -> torch.Tensor:
+    """Weight image of the bf16 head kernel (srgen_kernels_bf16.hip) from the (3, 96, 9, 9) weight, on the device: bf16 units
+    of 8 [ky 9][g 6][h 2][n 32], ci = 16 g + 8 h + e, n = 3 kx + co (27 of 32 used).  Data movement and one rounding."""
+    t = w.detach().permute(2, 1, 3, 0).reshape(9, 6, 2, 8, 27)                 # ky, (g, h, e), (kx, co)
+    img = torch.zeros((9, 6, 2, 32, 8), dtype=torch.bfloat16, device=w.device)
+    img[:, :, :, :27, :] = t.permute(0, 1, 2, 4, 3).to(torch.bfloat16)
+    return img
+
+
 @_timed("9x9 stem / head")
 def head_forward(v: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """``F.conv2d(v, w, b, padding=4)[:, :, :125, :125]`` (Generator.py:71,80): NHWC (n, 128, 128, 96) -> NCHW (n, 3, 125, 125)."""
     _chk_nhwc("v", v)
     n = v.shape[0]
     y = torch.empty((n, 3, 125, 125), dtype=torch.float32, device=v.device)
+    if _bf(v):
+        pack = head_pack_bf16(w)
+        with torch.cuda.device(v.device):
+            _lib.check(_lib.lib().srgen_head_nhwc_bf16(v.data_ptr(), pack.data_ptr(), b.detach().data_ptr(), y.data_ptr(), n,
+                                                       _stream(v)))
+        return y
     split = conv_path() == "split"
     pack = head_pack_split(w) if split else head_pack(w)
     fn = _lib.lib().srgen_head_nhwc_split if split else _lib.lib().srgen_head_nhwc
@@ -707,8 +804,9 @@ def chan_attn_forward(x: torch.Tensor, ca: torch.nn.Module):
     pool = torch.empty((n, 16, 96), dtype=torch.float32, device=x.device)
     scale = torch.empty((n, 96), dtype=torch.float32, device=x.device)
     fc = ca.fc
+    op = _lib.lib().srgen_chan_attn_nhwc_bf16 if _bf(x) else _lib.lib().srgen_chan_attn_nhwc
     with torch.cuda.device(x.device):
-        _lib.check(_lib.lib().srgen_chan_attn_nhwc(y.data_ptr(), fc[0].weight.data_ptr(), fc[0].bias.data_ptr(),
+        _lib.check(op(y.data_ptr(), fc[0].weight.data_ptr(), fc[0].bias.data_ptr(),
                                                    fc[2].weight.data_ptr(), fc[2].bias.data_ptr(), pool.data_ptr(),
                                                    scale.data_ptr(), n, _stream(x)))
     return y, {"x": x, "pool": pool, "scale": scale}
@@ -727,8 +825,11 @@ def chan_attn_backward(dy: torch.Tensor, saved: dict, ca: torch.nn.Module, ws: W
     d = (lambda k: into[k]) if into is not None else (lambda k: None)
     g = {"fc.0.weight": _out(d("fc.0.weight"), (12, 96, 1, 1), dev), "fc.0.bias": _out(d("fc.0.bias"), (12,), dev),
          "fc.2.weight": _out(d("fc.2.weight"), (96, 12, 1, 1), dev), "fc.2.bias": _out(d("fc.2.bias"), (96,), dev)}
+    if dy.dtype != x.dtype:
+        raise RuntimeError("chan_attn_backward: operands of one storage type")
+    op = L.srgen_chan_attn_bwd_bf16 if _bf(x) else L.srgen_chan_attn_bwd
     with torch.cuda.device(dev):
-        _lib.check(L.srgen_chan_attn_bwd(x.data_ptr(), dy.data_ptr(), saved["pool"].data_ptr(), saved["scale"].data_ptr(), n,
+        _lib.check(op(x.data_ptr(), dy.data_ptr(), saved["pool"].data_ptr(), saved["scale"].data_ptr(), n,
                                          fc[0].weight.data_ptr(), fc[0].bias.data_ptr(), fc[2].weight.data_ptr(),
                                          fc[2].bias.data_ptr(), dx.data_ptr(), g["fc.0.weight"].data_ptr(),
                                          g["fc.0.bias"].data_ptr(), g["fc.2.weight"].data_ptr(), g["fc.2.bias"].data_ptr(),
@@ -782,7 +883,9 @@ class GeneratorGrad:
         S = {"lr": x, "blocks": []}
         stats = []                                                           # batch statistics in module order
         w = g.input[0].weight
-        S["x1_pre"] = conv9x9_c3(x, w.detach().permute(1, 2, 3, 0).reshape(243, 96).contiguous(), g.input[0].bias.detach(), 64, False)
+        act_dtype = torch.bfloat16 if _CONV_PRECISION[0] == "bf16" else torch.float32
+        S["x1_pre"] = conv9x9_c3(x, w.detach().permute(1, 2, 3, 0).reshape(243, 96).contiguous(), g.input[0].bias.detach(), 64, False,
+                                 out_dtype=act_dtype)
         x1 = prelu_scalar(S["x1_pre"], g.input[1].weight.detach())
         cur = x1
         for m in g.blocks:
@@ -839,7 +942,7 @@ class GeneratorGrad:
         if side is not None:
             S["v"].record_stream(side)
             dsr.record_stream(side)
-        dv = conv9x9_c3(dsr, w.permute(0, 2, 3, 1).reshape(243, 96).contiguous(), None, 128, True)
+        dv = conv9x9_c3(dsr, w.permute(0, 2, 3, 1).reshape(243, 96).contiguous(), None, 128, True, out_dtype=S["v"].dtype)
         # output[0..1]: conv3x3 at 128 x 128 + scalar PReLU (Generator.py:69-70)
         dv_pre, ds = prelu_scalar_bwd(S["v_pre"], dv, g.output[1].weight.detach(), ws)
         put("output.1.weight", ds)
@@ -905,17 +1008,18 @@ class PretrainStep(GeneratorGrad):
     superresolution_amd/autograd.py; this object is the fused form: loss and loss gradient from two kernels, gradients
     written straight into one flat buffer).  Gradients land in ``p.grad`` (views of ``optimizer.flat_grad``, so the
     reference's ``grad_norm`` (train.py:23-28) and a data-parallel all-reduce of ONE 12.86 MB buffer work unchanged),
-    BatchNorm running statistics are updated as ``nn.BatchNorm2d`` does.  Tensors are fp32; ``precision`` picks the 3x3
-    conv products: "fp32", "f16" (16-bit operands, fp32 accumulation: what the reference's bf16 autocast does to its
-    convs) or "auto" (default: "f16" when ``step`` is called inside ``torch.autocast`` with a 16-bit dtype, as train.py:91
+    BatchNorm running statistics are updated as ``nn.BatchNorm2d`` does.  ``precision`` picks the arithmetic: "fp32"
+    (fp32 tensors, fp32-accurate 3x3 conv products), "f16" (fp32 tensors, 16-bit operands in the 3x3 convs, fp32
+    accumulation), "bf16" (the 16-bit step: bf16 activation and gradient tensors, bf16 products, fp32 accumulation -- the
+    storage and product types of the reference's own autocast step) or "auto" (default: "f16" when ``step`` is called inside ``torch.autocast`` with a 16-bit dtype, as train.py:91
     calls the generator, else "fp32"; see ``conv_precision``).  With
     ``world_size > 1`` (one process per GPU, ``torch.distributed`` initialised) ``step`` averages ``flat_grad`` over the
     ranks with one all-reduce before the update, as DistributedDataParallel would."""
 
     def __init__(self, generator, lr: float = 1e-4, ssim_weight: float = 0.1, l1_weight: float = 1.0, group=None,
                  precision: str = "auto"):
-        if precision not in ("auto", "fp32", "f16"):
-            raise RuntimeError(f"precision '{precision}': expected auto, fp32 or f16")
+        if precision not in ("auto", "fp32", "f16", "bf16"):
+            raise RuntimeError(f"precision '{precision}': expected auto, fp32, f16 or bf16")
         self.precision = precision
         super().__init__(generator)
         self.optimizer = FlatAdamW(generator.parameters(), lr=lr)

@@ -1,0 +1,216 @@
+"""GPU: the 16-bit pre-train step (bf16 activation / gradient tensors, `precision="bf16"`; the storage and product types of
+the reference's own step under torch.autocast(bfloat16), train.py:91).
+
+(a) Every bf16 operator against its fp32 namesake ON THE SAME VALUES (inputs that are exactly representable in bf16): products
+    of bf16 numbers are exact in fp32 and both sides accumulate in fp32, so tensor outputs may differ by the final rounding to
+    bf16 only (2^-8 relative per element, stated as 2^-7 of the tensor's maximum to admit cancellation) and parameter
+    gradients (fp32 on both sides) by summation order (1e-5 of max).
+(b) One whole step against ONE step of the real reference run both ways (tests/golden/train_step.npz: fp32;
+    train_step_autocast.npz: inside torch.autocast(bfloat16) -- make_golden_bwd.py): the bf16 step has to be as close to the
+    fp32 step as the reference's own autocast step is (same arithmetic class): loss and per-tensor gradient deviation within
+    1.5x the reference autocast's (measured: see the printed table)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from test_gpu_training import _hash_tensor, _nhwc, _resblock, _sample_rel, _step_batch
+
+pytestmark = pytest.mark.gpu
+ROUND = 2.0 ** -7       # of the tensor's max: one bf16 rounding of the stored result
+SUMS = 1e-5             # fp32 outputs: summation order only
+
+
+def _b(t):
+    """Round to bf16: (the bf16 tensor, the same values as fp32)."""
+    tb = t.to(torch.bfloat16).contiguous()
+    return tb, tb.float().contiguous()
+
+
+def _close_rounded(got_bf16, ref_f32, what, tol=ROUND):
+    assert got_bf16.dtype == torch.bfloat16, what
+    err = float((got_bf16.float() - ref_f32).abs().max() / ref_f32.abs().max())
+    print(f"  {what}: {err:.2e} of max")
+    assert err <= tol, (what, err)
+
+
+def _close_sums(got, ref, what, tol=SUMS):
+    assert got.dtype == torch.float32, what
+    err = float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+    print(f"  {what}: {err:.2e} of max")
+    assert err <= tol, (what, err)
+
+
+@pytest.mark.parametrize("hw,n", [(64, 3), (128, 2)])
+def test_conv3x3_bf16_forward_dgrad_wgrad_vs_the_fp32_operators(hw, n):
+    from superresolution_amd import training as T
+    dev = torch.device("cuda")
+    ws = T.Workspace(dev)
+    w = _hash_tensor(3, "w", (96, 96, 3, 3), -0.06, 0.06).to(torch.bfloat16).float().cuda()       # bf16-representable weights
+    bias = _hash_tensor(4, "b", (96,)).cuda()
+    xb, xf = _b(_nhwc(_hash_tensor(5, "x", (n, 96, hw, hw))).cuda())
+    gb, gf = _b((_nhwc(_hash_tensor(6, "g", (n, 96, hw, hw))) * 2.0 ** -20).cuda())               # a gradient-sized tensor
+    rb_, rf = _b((_nhwc(_hash_tensor(7, "r", (n, 96, hw, hw))) * 2.0 ** -20).cuda())
+    with T.conv_precision("bf16"):
+        yb = T.conv3x3(xb, T.conv_pack(w), bias)
+        dxb = T.conv3x3(gb, T.conv_pack(w, mode=1), res=rb_ if hw == 64 else None)
+        dwb, dbb = T.conv3x3_wgrad(xb, gb, ws)
+    with T.conv_precision("fp32"):
+        yf = T.conv3x3(xf, T.conv_pack(w), bias)
+        dxf = T.conv3x3(gf, T.conv_pack(w, mode=1), res=rf if hw == 64 else None, scale_input=True)
+        dwf, dbf = T.conv3x3_wgrad(xf, gf, ws)
+    _close_rounded(yb, yf, "conv forward")
+    _close_rounded(dxb, dxf, "conv data gradient (+ residual)")
+    _close_sums(dwb, dwf, "weight gradient")
+    _close_sums(dbb, dbf, "bias gradient")
+
+
+def test_upsample_conv_bf16_with_pixel_shuffle_vs_fp32():
+    from superresolution_amd import training as T
+    w = _hash_tensor(8, "wu", (384, 96, 3, 3), -0.06, 0.06).to(torch.bfloat16).float().cuda()
+    bias = _hash_tensor(9, "bu", (384,)).cuda()
+    xb, xf = _b(_nhwc(_hash_tensor(10, "xu", (2, 96, 64, 64))).cuda())
+    with T.conv_precision("bf16"):
+        yb = T.conv3x3(xb, T.conv_pack(w), bias, cout_blocks=4, shuffle=True)
+        gb, gf = _b(_nhwc(_hash_tensor(11, "gu", (2, 96, 64, 64))).cuda())
+        db = T.conv3x3(gb, T.conv_pack(w, mode=1, block=2))
+    with T.conv_precision("fp32"):
+        yf = T.conv3x3(xf, T.conv_pack(w), bias, cout_blocks=4, shuffle=True)
+        df = T.conv3x3(gf, T.conv_pack(w, mode=1, block=2), scale_input=True)
+    assert yb.shape == (2, 128, 128, 96)
+    _close_rounded(yb, yf, "upsample conv + PixelShuffle")
+    _close_rounded(db, df, "data gradient of cout block 2")
+
+
+def test_batchnorm_prelu_bf16_forward_backward_vs_fp32():
+    from superresolution_amd import training as T
+    dev = torch.device("cuda")
+    ws = T.Workspace(dev)
+    rb = _resblock().cuda()
+    gamma, beta, slope = rb.block[1].weight.detach(), rb.block[1].bias.detach(), rb.block[2].weight.detach()
+    cb, cf = _b(_nhwc(_hash_tensor(21, "c", (3, 96, 64, 64), -2.0, 3.0)).cuda())
+    rb_, rf = _b(_nhwc(_hash_tensor(22, "res", (3, 96, 64, 64))).cuda())
+    db_, df = _b((_nhwc(_hash_tensor(23, "d", (3, 96, 64, 64))) * 2.0 ** -18).cuda())
+    for kw_b, kw_f, what in (({"slope": slope}, {"slope": slope}, "BatchNorm + PReLU"),
+                             ({"res": rb_, "res_factor": 0.1}, {"res": rf, "res_factor": 0.1}, "BatchNorm + residual")):
+        ob, sb = T.bn_train_fwd(cb, gamma, beta, ws, **kw_b)
+        of, sf = T.bn_train_fwd(cf, gamma, beta, ws, **kw_f)
+        _close_rounded(ob, of, what + " forward")
+        _close_sums(sb, sf, what + " batch statistics", 1e-6)
+    for sl, scale in ((slope, 1.0), (None, 0.1)):
+        dcb, dgb, dbb, dsb = T.bn_train_bwd(cb, db_, sb, gamma, beta, ws, slope=sl, dout_scale=scale)
+        dcf, dgf, dbf, dsf = T.bn_train_bwd(cf, df, sf, gamma, beta, ws, slope=sl, dout_scale=scale)
+        _close_rounded(dcb, dcf, "BatchNorm backward dc")
+        _close_sums(dgb, dgf, "dgamma")
+        _close_sums(dbb, dbf, "dbeta")
+        if sl is not None:
+            _close_sums(dsb, dsf, "dslope")
+
+
+def test_scalar_prelu_and_channel_attention_bf16_vs_fp32():
+    from superresolution_amd import Generator, training as T, weights as W
+    dev = torch.device("cuda")
+    ws = T.Workspace(dev)
+    g = Generator()
+    g.load_state_dict(W.synthetic_state_dict(0))
+    g = g.cuda()
+    xb, xf = _b(_nhwc(_hash_tensor(31, "x", (3, 96, 64, 64), -1.0, 2.0)).cuda())
+    db_, df = _b((_nhwc(_hash_tensor(32, "d", (3, 96, 64, 64))) * 2.0 ** -19).cuda())
+    d2b, d2f = _b((_nhwc(_hash_tensor(33, "d2", (3, 96, 64, 64))) * 2.0 ** -19).cuda())
+    slope = g.input[1].weight.detach()
+    _close_rounded(T.prelu_scalar(xb, slope), T.prelu_scalar(xf, slope), "scalar PReLU forward")
+    dxb, dsb = T.prelu_scalar_bwd(xb, db_, slope, ws, dy2=d2b)
+    dxf, dsf = T.prelu_scalar_bwd(xf, df, slope, ws, dy2=d2f)
+    _close_rounded(dxb, dxf, "scalar PReLU backward")
+    _close_sums(dsb, dsf, "dslope")
+    ca = g.blocks[8]
+    yb, Sb = T.chan_attn_forward(xb, ca)
+    yf, Sf = T.chan_attn_forward(xf, ca)
+    _close_rounded(yb, yf, "channel attention forward")
+    _close_sums(Sb["scale"], Sf["scale"], "attention scales", 1e-6)
+    dxb, gb = T.chan_attn_backward(db_, Sb, ca, ws)
+    dxf, gf = T.chan_attn_backward(df, Sf, ca, ws)
+    _close_rounded(dxb, dxf, "channel attention backward")
+    for k in gb:
+        _close_sums(gb[k], gf[k], "attention " + k)
+
+
+def test_stem_and_head_bf16_vs_fp32():
+    from superresolution_amd import Generator, training as T, weights as W
+    dev = torch.device("cuda")
+    ws = T.Workspace(dev)
+    g = Generator()
+    g.load_state_dict(W.synthetic_state_dict(0))
+    g = g.cuda()
+    lr, _ = _step_batch()
+    w = g.input[0].weight.detach()
+    wm = w.permute(1, 2, 3, 0).reshape(243, 96).contiguous()
+    x1f = T.conv9x9_c3(lr, wm, g.input[0].bias.detach(), 64, False)
+    x1b = T.conv9x9_c3(lr, wm, g.input[0].bias.detach(), 64, False, out_dtype=torch.bfloat16)
+    _close_rounded(x1b, x1f, "stem forward")
+    # stem weight gradient: bf16 activation gradient against the fp32 image
+    db_, df = _b((_nhwc(_hash_tensor(41, "d", (4, 96, 64, 64))) * 2.0 ** -18).cuda())
+    rb_, bb = T.conv9x9_c3_wgrad(db_, lr, ws, flip=False, want_bias=True)
+    rf, bf = T.conv9x9_c3_wgrad(df, lr, ws, flip=False, want_bias=True)
+    _close_sums(rb_, rf, "stem weight gradient")
+    _close_sums(bb, bf, "stem bias gradient")
+    # head: bf16 (n, 128, 128, 96) -> fp32 image; its weights are rounded to bf16 by the 16-bit step, so compare on those
+    wh = g.output[2].weight.detach().to(torch.bfloat16).float()
+    vb, vf = _b(_nhwc(_hash_tensor(42, "v", (2, 96, 128, 128))).cuda())
+    yb = T.head_forward(vb, wh, g.output[2].bias)
+    yf = T.head_forward(vf, wh, g.output[2].bias)
+    _close_sums(yb, yf, "head forward")
+    # head data gradient: fp32 image gradient -> bf16 (n, 128, 128, 96)
+    dsr = (_hash_tensor(43, "dsr", (2, 3, 125, 125)) * 2.0 ** -16).cuda()
+    whm = g.output[2].weight.detach().permute(0, 2, 3, 1).reshape(243, 96).contiguous()
+    _close_rounded(T.conv9x9_c3(dsr, whm, None, 128, True, out_dtype=torch.bfloat16), T.conv9x9_c3(dsr, whm, None, 128, True),
+                   "head data gradient")
+
+
+def test_pretrain_step_bf16_vs_reference_fp32_and_autocast_golden():
+    """(b) of the module docstring."""
+    from superresolution_amd import Generator, training as T, weights as W
+    g32 = np.load(os.path.join(GOLDEN, "train_step.npz"))
+    gac = np.load(os.path.join(GOLDEN, "train_step_autocast.npz"))
+    lr, hr = _step_batch()
+    g = Generator()
+    g.load_state_dict(W.synthetic_state_dict(0))
+    g = g.cuda().train()
+    step = T.PretrainStep(g, lr=1e-4, precision="bf16")
+    loss = float(step.forward_backward(lr, hr))
+    ref_loss, ac_loss = float(g32["loss"]), float(gac["loss"])
+    print("loss: fp32 reference", ref_loss, "reference autocast", ac_loss, "this bf16 step", loss)
+    assert abs(loss - ref_loss) <= 1.5 * abs(ac_loss - ref_loss) + 1e-5 * abs(ref_loss)
+    P = dict(g.named_parameters())
+    ratios = []
+    for k in g32.files:
+        if not k.startswith("grad_sample_"):
+            continue
+        v = P[k[len("grad_sample_"):]].grad.detach().flatten()[::7].cpu().numpy()
+        ours, theirs = _sample_rel(v, g32[k]), _sample_rel(gac[k], g32[k])
+        print(f"  {k}: this step {ours:.2e}, reference autocast {theirs:.2e}")
+        assert ours <= 1.5 * theirs and ours <= 6e-2, (k, ours, theirs)
+        ratios.append(ours / theirs)
+    print("  this step's deviation / the reference autocast's: median", float(np.median(ratios)), "max", max(ratios))
+    assert float(np.median(ratios)) <= 1.0
+    for p in g.parameters():
+        assert p.grad.dtype == torch.float32 and bool(torch.isfinite(p.grad).all())
+
+
+def test_pretrain_steps_bf16_reduce_the_loss_like_the_fp32_step():
+    """Twelve optimizer steps on one batch: the bf16 step's loss follows the fp32 step's (same data, same initial weights)."""
+    from superresolution_amd import Generator, training as T, weights as W
+    lr, hr = _step_batch()
+    finals = {}
+    for prec in ("fp32", "bf16"):
+        g = Generator()
+        g.load_state_dict(W.synthetic_state_dict(0))
+        g = g.cuda().train()
+        step = T.PretrainStep(g, lr=1e-4, precision=prec)
+        losses = [float(step.step(lr, hr)) for _ in range(12)]
+        finals[prec] = losses
+        assert losses[-1] < losses[0]
+    print("loss after 12 steps: fp32", finals["fp32"][-1], "bf16", finals["bf16"][-1])
+    assert abs(finals["bf16"][-1] - finals["fp32"][-1]) <= 2e-3 * abs(finals["fp32"][-1])

@@ -48,6 +48,10 @@ def test_argument_errors_without_gpu():
     assert L.srgen_split_pack_many(1, None, None, None, None, None, None) == -1 and b"NULL" in L.srgen_last_error()
     assert L.srgen_conv3x3_nhwc_f16(None, None, None, None, None, 1, 64, 1, 0, None, None) == -1
     assert L.srgen_conv3x3_wgrad_f16(None, None, 1, 64, None, None, None, None, 0, None) == -1
+    assert L.srgen_bf16_pack_many(0, None, None, None, None, None, None) == -1 and b"count" in L.srgen_last_error()
+    assert L.srgen_conv3x3_nhwc_bf16(None, None, None, None, None, 1, 64, 1, 0, None) == -1
+    assert L.srgen_conv3x3_wgrad_bf16(None, None, 1, 64, None, None, None, 0, None) == -1
+    assert L.srgen_bn_train_bwd_bf16(None, None, None, None, None, None, 1.0, None, None, None, None, 0, None, 0, None) == -1
 
 
 def test_conv_precision_switch_on_the_host():
@@ -57,9 +61,12 @@ def test_conv_precision_switch_on_the_host():
     assert T.resolve_precision("auto") == "fp32" and T.resolve_precision("f16") == "f16"
     with T.conv_precision("f16"):
         assert T._CONV_PRECISION[0] == "f16"
-        with pytest.raises(RuntimeError, match="expected fp32 or f16"):
-            with T.conv_precision("bf16"):
+        with pytest.raises(RuntimeError, match="expected fp32, f16 or bf16"):
+            with T.conv_precision("fp8"):
                 pass
+        assert T._CONV_PRECISION[0] == "f16"
+        with T.conv_precision("bf16"):
+            assert T._CONV_PRECISION[0] == "bf16"
         assert T._CONV_PRECISION[0] == "f16"
     assert T._CONV_PRECISION[0] == "fp32"
     with pytest.raises(RuntimeError, match="precision"):

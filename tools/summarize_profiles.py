@@ -56,8 +56,16 @@ def main():
         json.dump(merged, open(os.path.join(dst, f"{tag}_{dt}_pmc.json"), "w"), indent=1, sort_keys=True)
         # trunk conv: launch-weighted mean of HBM bytes per launch
         fetch = write = n_f = n_w = 0.0
+        busy = gui = wait = wavec = 0.0
         for k, d in merged.items():
             if is_trunk(k, dt):
+                if "SQ_VALU_MFMA_BUSY_CYCLES" in d and "GRBM_GUI_ACTIVE" in d:
+                    n = d["GRBM_GUI_ACTIVE"]["n"]
+                    busy += d["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] * n
+                    gui += d["GRBM_GUI_ACTIVE"]["mean"] * n
+                    if "SQ_WAIT_INST_ANY" in d and "SQ_WAVE_CYCLES" in d:
+                        wait += d["SQ_WAIT_INST_ANY"]["mean"] * n
+                        wavec += d["SQ_WAVE_CYCLES"]["mean"] * n
                 if "FETCH_SIZE" in d:
                     fetch += d["FETCH_SIZE"]["mean"] * d["FETCH_SIZE"]["n"]
                     n_f += d["FETCH_SIZE"]["n"]
@@ -74,6 +82,10 @@ def main():
             out = {"path": path, "conv3x3_trunk_hbm_bytes_per_launch": round(rd + wr),
                    "read_bytes": round(rd), "write_bytes": round(wr), "launches_sampled": int(n_f),
                    "batch": 256,
+                   # matrix-pipe busy cycles summed over the chip's 1024 SIMDs / (1024 x kernel cycles);
+                   # GRBM_GUI_ACTIVE is summed over the 8 XCDs, hence / 8
+                   "mfma_busy_frac": round(busy / (1024.0 * gui / 8.0), 4) if gui else None,
+                   "wait_inst_frac": round(wait / wavec, 4) if wavec else None,
                    "source": f"profiles/{tag}_{dt}_pmc.json: FETCH_SIZE (KB, x2 gfx950 correction for 16 B/lane "
                              "reads) + WRITE_SIZE (KB), separate rocprofv3 --pmc passes, launch-weighted mean "
                              "over the 33 trunk conv3x3 launches of one batch-256 forward"}
