@@ -100,39 +100,63 @@ struct StemArgs {
 
 // ---- storage types of the training operators' activation / gradient tensors ------------------------------------
 // float (the fp32 and f16-product steps) or bf16 (the 16-bit step: the reference's autocast dtype, train.py:91).  The
-// elementwise and reduction kernels are templates over the storage type and compute in fp32: a thread's unit is four
-// consecutive channels = one 16-byte (fp32) or 8-byte (bf16) access.
+// elementwise and reduction kernels are templates over the storage type and compute in fp32: a thread's unit is one
+// 16-byte access = four (fp32) or eight (bf16) consecutive channels.
 struct bf16_t { unsigned short bits; };
-template <typename T> __device__ __forceinline__ void ld4(const T* p, float (&o)[4]);
-template <> __device__ __forceinline__ void ld4<float>(const float* p, float (&o)[4])
+// elements of one 16-byte access: a thread's unit in the elementwise kernels
+template <typename T> struct StoreVec { static constexpr int N = 4; };
+template <> struct StoreVec<bf16_t> { static constexpr int N = 8; };
+__device__ __forceinline__ void ldv(const float* p, float (&o)[4])
 {
     typedef float f4 __attribute__((ext_vector_type(4)));
     const f4 v = *(const f4*)p;
     o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
 }
-template <> __device__ __forceinline__ void ld4<bf16_t>(const bf16_t* p, float (&o)[4])
+__device__ __forceinline__ void ldv(const bf16_t* p, float (&o)[8])
 {
-    typedef unsigned u2 __attribute__((ext_vector_type(2)));
-    const u2 v = *(const u2*)p;
-    o[0] = __builtin_bit_cast(float, v.x << 16); o[1] = __builtin_bit_cast(float, v.x & 0xffff0000u);
-    o[2] = __builtin_bit_cast(float, v.y << 16); o[3] = __builtin_bit_cast(float, v.y & 0xffff0000u);
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    const u4 v = *(const u4*)p;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        o[2 * k] = __builtin_bit_cast(float, v[k] << 16);
+        o[2 * k + 1] = __builtin_bit_cast(float, v[k] & 0xffff0000u);
+    }
 }
-template <typename T> __device__ __forceinline__ void st4(T* p, const float (&o)[4]);
-template <> __device__ __forceinline__ void st4<float>(float* p, const float (&o)[4])
+__device__ __forceinline__ void stv(float* p, const float (&o)[4])
 {
     typedef float f4 __attribute__((ext_vector_type(4)));
     *(f4*)p = f4{o[0], o[1], o[2], o[3]};
 }
-template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, const float (&o)[4])
+__device__ __forceinline__ unsigned pack2_bf16(float lo, float hi)         // round to nearest even
 {
     typedef __bf16 b2 __attribute__((ext_vector_type(2)));
-    typedef unsigned u2 __attribute__((ext_vector_type(2)));
-    const b2 lo = {(__bf16)o[0], (__bf16)o[1]}, hi = {(__bf16)o[2], (__bf16)o[3]};     // round to nearest even
-    *(u2*)p = u2{__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
+    const b2 t = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(unsigned, t);
 }
-template <typename T> __device__ __forceinline__ float ld1(const T* p);
-template <> __device__ __forceinline__ float ld1<float>(const float* p) { return *p; }
-template <> __device__ __forceinline__ float ld1<bf16_t>(const bf16_t* p) { return __builtin_bit_cast(float, (unsigned)p->bits << 16); }
+__device__ __forceinline__ void stv(bf16_t* p, const float (&o)[8])
+{
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    *(u4*)p = u4{pack2_bf16(o[0], o[1]), pack2_bf16(o[2], o[3]), pack2_bf16(o[4], o[5]), pack2_bf16(o[6], o[7])};
+}
+// V consecutive fp32 values (per-channel constants) with 16-byte loads
+template <int V> __device__ __forceinline__ void ldf(const float* p, float (&o)[V])
+{
+    typedef float f4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int k = 0; k < V / 4; ++k) {
+        const f4 v = *(const f4*)(p + 4 * k);
+        o[4 * k] = v.x; o[4 * k + 1] = v.y; o[4 * k + 2] = v.z; o[4 * k + 3] = v.w;
+    }
+}
+// four consecutive channels (8-byte access for bf16): kernels whose lane layout is fixed by an MFMA tile
+__device__ __forceinline__ void st4(float* p, const float (&o)[4]) { stv(p, o); }
+__device__ __forceinline__ void st4(bf16_t* p, const float (&o)[4])
+{
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    *(u2*)p = u2{pack2_bf16(o[0], o[1]), pack2_bf16(o[2], o[3])};
+}
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const bf16_t* p) { return __builtin_bit_cast(float, (unsigned)p->bits << 16); }
 
 // ---- channel attention: pool finish + FC + sigmoid + in-place scale ---------------------
 struct ChanAttnArgs {

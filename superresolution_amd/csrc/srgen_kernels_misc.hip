@@ -323,45 +323,48 @@ constexpr int BN_THREADS = 240;                // 10 pixel rows x 24 float4 chan
 template <typename T>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ t, size_t npix, double* partial)
 {
-    __shared__ double red[10][2][96];
+    constexpr int V = StoreVec<T>::N, CPP = 96 / V, ROWS = BN_THREADS / CPP;     // 24 x 10 (fp32) or 12 x 20 (bf16)
+    __shared__ float red[ROWS][2][96];          // (a thread's sums are fp32; they are added in fp64 below)
     const int tid = threadIdx.x;
     if (tid < BN_THREADS) {
-        const int c4 = tid % 24, row = tid / 24;
+        const int cg = tid % CPP, row = tid / CPP;
         const size_t per = (npix + gridDim.x - 1) / gridDim.x;
         const size_t p0 = (size_t)blockIdx.x * per, p1 = p0 + per < npix ? p0 + per : npix;
-        float sx[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
-        size_t p = p0 + row;
-        for (; p + 30 < p1; p += 40) {                          // four loads in flight per thread
-            float v[4][4];
+        float sx[V], sq[V];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) ld4(t + (p + 10 * u) * 96 + c4 * 4, v[u]);
+        for (int e = 0; e < V; ++e) sx[e] = sq[e] = 0.f;
+        size_t p = p0 + row;
+        for (; p + 3 * ROWS < p1; p += 4 * ROWS) {              // four loads in flight per thread
+            float v[4][V];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ldv(t + (p + ROWS * u) * 96 + cg * V, v[u]);
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
+                for (int e = 0; e < V; ++e) {
                     sx[e] += v[u][e];
                     sq[e] += v[u][e] * v[u][e];
                 }
         }
-        for (; p < p1; p += 10) {
-            float v[4];
-            ld4(t + p * 96 + c4 * 4, v);
+        for (; p < p1; p += ROWS) {
+            float v[V];
+            ldv(t + p * 96 + cg * V, v);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+            for (int e = 0; e < V; ++e) {
                 sx[e] += v[e];
                 sq[e] += v[e] * v[e];
             }
         }
-        for (int e = 0; e < 4; ++e) {
-            red[row][0][c4 * 4 + e] = (double)sx[e];
-            red[row][1][c4 * 4 + e] = (double)sq[e];
+        for (int e = 0; e < V; ++e) {
+            red[row][0][cg * V + e] = sx[e];
+            red[row][1][cg * V + e] = sq[e];
         }
     }
     __syncthreads();
     if (tid < 192) {
         const int k = tid / 96, c = tid % 96;
         double a = 0.0;
-        for (int r = 0; r < 10; ++r) a += red[r][k][c];
+        for (int r = 0; r < ROWS; ++r) a += (double)red[r][k][c];
         partial[(size_t)blockIdx.x * 192 + tid] = a;
     }
 }
@@ -410,27 +413,30 @@ __global__ __launch_bounds__(768) void bn_final_kernel(const double* partial, in
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* t, T* out, const float* __restrict__ scale_shift,
                                                        const float* __restrict__ slope, const T* __restrict__ res,
-                                                       float res_factor, size_t n4)
+                                                       float res_factor, size_t nvec)
 {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-        const int c = (int)(i % 24) * 4;
-        float v[4];
-        ld4(t + i * 4, v);
-        const float4 sc = *reinterpret_cast<const float4*>(scale_shift + c);
-        const float4 sh = *reinterpret_cast<const float4*>(scale_shift + 96 + c);
-        v[0] = fmaf(v[0], sc.x, sh.x); v[1] = fmaf(v[1], sc.y, sh.y); v[2] = fmaf(v[2], sc.z, sh.z); v[3] = fmaf(v[3], sc.w, sh.w);
+    constexpr int V = StoreVec<T>::N, CPP = 96 / V;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % CPP) * V;
+        float v[V], sc[V], sh[V];
+        ldv(t + i * V, v);
+        ldf<V>(scale_shift + c, sc);
+        ldf<V>(scale_shift + 96 + c, sh);
+#pragma unroll
+        for (int e = 0; e < V; ++e) v[e] = fmaf(v[e], sc[e], sh[e]);
         if (slope) {                                             // PReLU(ch), Generator.py:36
-            const float4 sl = *reinterpret_cast<const float4*>(slope + c);
-            v[0] = v[0] >= 0.f ? v[0] : v[0] * sl.x; v[1] = v[1] >= 0.f ? v[1] : v[1] * sl.y;
-            v[2] = v[2] >= 0.f ? v[2] : v[2] * sl.z; v[3] = v[3] >= 0.f ? v[3] : v[3] * sl.w;
+            float sl[V];
+            ldf<V>(slope + c, sl);
+#pragma unroll
+            for (int e = 0; e < V; ++e) v[e] = v[e] >= 0.f ? v[e] : v[e] * sl[e];
         }
         if (res) {                                               // x + 0.1 * block(x) (:42) / x1 + mid(x2) (:78)
-            float r[4];
-            ld4(res + i * 4, r);
+            float r[V];
+            ldv(res + i * V, r);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaf(res_factor, v[e], r[e]);
+            for (int e = 0; e < V; ++e) v[e] = fmaf(res_factor, v[e], r[e]);
         }
-        st4(out + i * 4, v);
+        stv(out + i * V, v);
     }
 }
 
@@ -439,24 +445,28 @@ template <typename T>
 __global__ __launch_bounds__(256) void pool_partial_kernel(const T* __restrict__ t, int hw, int parts,
                                                            float* pool_partial)
 {
-    __shared__ float red[10][96];
+    constexpr int V = StoreVec<T>::N, CPP = 96 / V, ROWS = BN_THREADS / CPP;
+    __shared__ float red[ROWS][96];
     const int tid = threadIdx.x;
     const int per = hw / parts;
     const size_t p0 = (size_t)blockIdx.x * per;                  // blockIdx.x = image * parts + part
     if (tid < BN_THREADS) {
-        const int c4 = tid % 24, row = tid / 24;
-        float s[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int p = row; p < per; p += 10) {
-            float v[4];
-            ld4(t + (p0 + p) * 96 + c4 * 4, v);
-            s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+        const int cg = tid % CPP, row = tid / CPP;
+        float s[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) s[e] = 0.f;
+        for (int p = row; p < per; p += ROWS) {
+            float v[V];
+            ldv(t + (p0 + p) * 96 + cg * V, v);
+#pragma unroll
+            for (int e = 0; e < V; ++e) s[e] += v[e];
         }
-        for (int e = 0; e < 4; ++e) red[row][c4 * 4 + e] = s[e];
+        for (int e = 0; e < V; ++e) red[row][cg * V + e] = s[e];
     }
     __syncthreads();
     if (tid < 96) {
         float a = 0.f;
-        for (int r = 0; r < 10; ++r) a += red[r][tid];
+        for (int r = 0; r < ROWS; ++r) a += red[r][tid];
         pool_partial[(size_t)blockIdx.x * 96 + tid] = a;
     }
 }
@@ -470,14 +480,15 @@ static hipError_t bn_train_t(T* t, size_t npix, const float* gamma, const float*
     if (!out) out = t;                                   // in place (the forward-values path)
     double* partial = static_cast<double*>(scratch);
     float* ss = reinterpret_cast<float*>(partial + (size_t)kBnBlocks * 192);
-    const int nb = npix < (size_t)kBnBlocks * 10 ? (int)((npix + 9) / 10) : kBnBlocks;
+    constexpr int ROWS = BN_THREADS / (96 / StoreVec<T>::N);       // pixel rows one workgroup reads at a time
+    const int nb = npix < (size_t)kBnBlocks * ROWS ? (int)((npix + ROWS - 1) / ROWS) : kBnBlocks;
     hipLaunchKernelGGL(bn_stats_kernel<T>, dim3(nb), dim3(256), 0, s, t, npix, partial);
     hipLaunchKernelGGL(bn_final_kernel, dim3(8), dim3(768), 0, s, partial, nb, (double)npix, gamma, beta, 1e-5f, ss,
                        batch_stats);
-    const size_t n4 = npix * 24;
-    const size_t want = (n4 + 255) / 256;
+    const size_t nvec = npix * (96 / StoreVec<T>::N);
+    const size_t want = (nvec + 255) / 256;
     hipLaunchKernelGGL(bn_apply_kernel<T>, dim3((unsigned)(want < 16384 ? want : 16384)), dim3(256), 0, s, t, out, ss, slope,
-                       res, res_factor, n4);
+                       res, res_factor, nvec);
     return hipGetLastError();
 }
 

@@ -81,7 +81,7 @@ int srgen_bn_train_fwd_bf16(const void* c, void* out, const float* gamma, const 
     if (!c || !out || !gamma || !beta || !batch_stats || !scratch) return fail(SRGEN_E_INVALID, "NULL argument");
     if (npix == 0) return fail(SRGEN_E_INVALID, "empty batch");
     if (scratch_bytes < bn_scratch_bytes()) return fail(SRGEN_E_WORKSPACE, "BatchNorm scratch too small");
-    if (((uintptr_t)c & 7) || ((uintptr_t)out & 7) || ((uintptr_t)res & 7)) return fail(SRGEN_E_INVALID, "operands must be 8-byte aligned");
+    if (!aligned16(c) || !aligned16(out) || !aligned16(res)) return fail(SRGEN_E_INVALID, "operands must be 16-byte aligned");
     HIP_TRY(launch_bn_train_bf16(const_cast<void*>(c), npix, gamma, beta, slope, res, res_factor, scratch, batch_stats,
                                  (hipStream_t)stream, out));
     return SRGEN_OK;
@@ -96,7 +96,7 @@ int srgen_bn_train_bwd_bf16(const void* c, const void* dout, const float* batch_
     if (slope && !dslope) return fail(SRGEN_E_INVALID, "slope without dslope");
     if (npix == 0) return fail(SRGEN_E_INVALID, "empty batch");
     if (scratch_bytes < bn_bwd_scratch_bytes()) return fail(SRGEN_E_WORKSPACE, "BatchNorm scratch too small");
-    if (((uintptr_t)c & 7) || ((uintptr_t)dout & 7) || ((uintptr_t)dc & 7)) return fail(SRGEN_E_INVALID, "operands must be 8-byte aligned");
+    if (!aligned16(c) || !aligned16(dout) || !aligned16(dc)) return fail(SRGEN_E_INVALID, "operands must be 16-byte aligned");
     HIP_TRY(launch_bn_train_bwd_bf16(c, dout, batch_stats, gamma, beta, slope, dout_scale, dc, dgamma, dbeta,
                                      slope ? dslope : nullptr, npix, scratch, (hipStream_t)stream));
     return SRGEN_OK;
@@ -106,8 +106,8 @@ int srgen_prelu_scalar_fwd_bf16(const void* x, const float* slope, void* y, size
 {
     if (numel == 0) return SRGEN_OK;
     if (!x || !slope || !y) return fail(SRGEN_E_INVALID, "NULL argument");
-    if ((numel & 3) || ((uintptr_t)x & 7) || ((uintptr_t)y & 7))
-        return fail(SRGEN_E_INVALID, "numel must be a multiple of 4, operands 8-byte aligned");
+    if ((numel & 7) || !aligned16(x) || !aligned16(y))
+        return fail(SRGEN_E_INVALID, "numel must be a multiple of 8, operands 16-byte aligned");
     HIP_TRY(launch_prelu_scalar_fwd_bf16(x, slope, y, numel, (hipStream_t)stream));
     return SRGEN_OK;
 }
@@ -116,8 +116,8 @@ int srgen_prelu_scalar_bwd_bf16(const void* x, const void* dy, const void* dy2, 
                                 size_t numel, void* scratch, size_t scratch_bytes, void* stream)
 {
     if (!x || !dy || !slope || !dx || !dslope || !scratch) return fail(SRGEN_E_INVALID, "NULL argument");
-    if (numel == 0 || (numel & 3) || ((uintptr_t)x & 7) || ((uintptr_t)dy & 7) || ((uintptr_t)dy2 & 7) || ((uintptr_t)dx & 7))
-        return fail(SRGEN_E_INVALID, "numel must be a positive multiple of 4, operands 8-byte aligned");
+    if (numel == 0 || (numel & 7) || !aligned16(x) || !aligned16(dy) || !aligned16(dy2) || !aligned16(dx))
+        return fail(SRGEN_E_INVALID, "numel must be a positive multiple of 8, operands 16-byte aligned");
     if (scratch_bytes < prelu_scratch_bytes()) return fail(SRGEN_E_WORKSPACE, "PReLU scratch too small");
     HIP_TRY(launch_prelu_scalar_bwd_bf16(x, dy, dy2, slope, dx, dslope, numel, scratch, (hipStream_t)stream));
     return SRGEN_OK;
@@ -179,6 +179,7 @@ int srgen_chan_attn_bwd_bf16(const void* x, const void* dy, const float* pool_pa
         return fail(SRGEN_E_INVALID, "NULL argument");
     if (n <= 0) return fail(SRGEN_E_INVALID, "batch %d", n);
     if (scratch_bytes < chan_attn_bwd_scratch_bytes(n)) return fail(SRGEN_E_WORKSPACE, "attention scratch too small");
+    if (!aligned16(x) || !aligned16(dy) || !aligned16(dx)) return fail(SRGEN_E_INVALID, "operands must be 16-byte aligned");
     HIP_TRY(launch_chan_attn_bwd_bf16(x, dy, pool_partial, scale, n, kLR * kLR, w1, b1, w2, b2, dx, dw1, db1, dw2, db2, scratch,
                                       (hipStream_t)stream));
     return SRGEN_OK;

@@ -803,30 +803,29 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const T* __restrict__
                                                            const float* __restrict__ beta, const float* __restrict__ slope,
                                                            float dscale, size_t npix, double* partial)
 {
-    __shared__ double red[10][3][96];
+    constexpr int V = StoreVec<T>::N, CPP = 96 / V, ROWS = BNB_THREADS / CPP;   // 24 x 10 (fp32) or 12 x 20 (bf16)
+    constexpr int STEP = ROWS * 96;
+    __shared__ float red[ROWS][3][96];          // (a thread's sums are fp32; they are added in fp64 below)
     const int tid = threadIdx.x;
     if (tid < BNB_THREADS) {
-        const int c4 = tid % 24, row = tid / 24;
-        float rstd[4], mr[4], pp[4], qq[4], sl[4];
+        const int cg = tid % CPP, row = tid / CPP;
+        float rstd[V], mr[V], pp[V], qq[V], sl[V];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            bn_consts(stats, gamma, beta, c4 * 4 + e, rstd[e], mr[e], pp[e], qq[e]);
-            sl[e] = slope ? slope[c4 * 4 + e] : 1.f;
+        for (int e = 0; e < V; ++e) {
+            bn_consts(stats, gamma, beta, cg * V + e, rstd[e], mr[e], pp[e], qq[e]);
+            sl[e] = slope ? slope[cg * V + e] : 1.f;
         }
         const size_t per = (npix + gridDim.x - 1) / gridDim.x;
         const size_t p0 = (size_t)blockIdx.x * per, p1 = p0 + per < npix ? p0 + per : npix;
-        float s_dz[4] = {0, 0, 0, 0}, s_dzx[4] = {0, 0, 0, 0}, s_sl[4] = {0, 0, 0, 0};
-        const T* cp = c + (p0 + row) * 96 + c4 * 4;
-        const T* dp = dt + (p0 + row) * 96 + c4 * 4;
-        const int iters = p1 > p0 + row ? (int)((p1 - p0 - row + 9) / 10) : 0;     // pixels of this thread
+        float s_dz[V], s_dzx[V], s_sl[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) s_dz[e] = s_dzx[e] = s_sl[e] = 0.f;
+        const T* cp = c + (p0 + row) * 96 + cg * V;
+        const T* dp = dt + (p0 + row) * 96 + cg * V;
+        const int iters = p1 > p0 + row ? (int)((p1 - p0 - row + ROWS - 1) / ROWS) : 0;     // pixels of this thread
         int it = 0;
-        for (; it + 4 <= iters; it += 4) {
-            float cv0[4], cv1[4], cv2[4], cv3[4], dv0[4], dv1[4], dv2[4], dv3[4];
-            ld4(cp, cv0); ld4(cp + 960, cv1); ld4(cp + 1920, cv2); ld4(cp + 2880, cv3);
-            ld4(dp, dv0); ld4(dp + 960, dv1); ld4(dp + 1920, dv2); ld4(dp + 2880, dv3);
-            cp += 3840; dp += 3840;
 #define BNB_ADD(cv, dv)                                                     \
-            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                 \
+            _Pragma("unroll") for (int e = 0; e < V; ++e) {                 \
                 const float xh = fmaf(cv[e], rstd[e], -mr[e]);              \
                 const float z = fmaf(cv[e], pp[e], qq[e]);                  \
                 const float d = dv[e] * dscale;                             \
@@ -836,27 +835,32 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const T* __restrict__
                 s_dzx[e] += dz * xh;                                        \
                 s_sl[e] += neg ? d * z : 0.f;                               \
             }
+        for (; it + 4 <= iters; it += 4) {                       // eight loads in flight per thread
+            float cv0[V], cv1[V], cv2[V], cv3[V], dv0[V], dv1[V], dv2[V], dv3[V];
+            ldv(cp, cv0); ldv(cp + STEP, cv1); ldv(cp + 2 * STEP, cv2); ldv(cp + 3 * STEP, cv3);
+            ldv(dp, dv0); ldv(dp + STEP, dv1); ldv(dp + 2 * STEP, dv2); ldv(dp + 3 * STEP, dv3);
+            cp += 4 * STEP; dp += 4 * STEP;
             BNB_ADD(cv0, dv0) BNB_ADD(cv1, dv1) BNB_ADD(cv2, dv2) BNB_ADD(cv3, dv3)
         }
         for (; it < iters; ++it) {
-            float cv[4], dv[4];
-            ld4(cp, cv);
-            ld4(dp, dv);
-            cp += 960; dp += 960;
+            float cv[V], dv[V];
+            ldv(cp, cv);
+            ldv(dp, dv);
+            cp += STEP; dp += STEP;
             BNB_ADD(cv, dv)
         }
 #undef BNB_ADD
-        for (int e = 0; e < 4; ++e) {
-            red[row][0][c4 * 4 + e] = (double)s_dz[e];
-            red[row][1][c4 * 4 + e] = (double)s_dzx[e];
-            red[row][2][c4 * 4 + e] = (double)s_sl[e];
+        for (int e = 0; e < V; ++e) {
+            red[row][0][cg * V + e] = s_dz[e];
+            red[row][1][cg * V + e] = s_dzx[e];
+            red[row][2][cg * V + e] = s_sl[e];
         }
     }
     __syncthreads();
     for (int k = tid; k < 288; k += 256) {
         const int which = k / 96, ch = k % 96;
         double a = 0.0;
-        for (int r = 0; r < 10; ++r) a += red[r][which][ch];
+        for (int r = 0; r < ROWS; ++r) a += (double)red[r][which][ch];
         partial[(size_t)blockIdx.x * 288 + k] = a;
     }
 }
@@ -909,34 +913,40 @@ __global__ __launch_bounds__(1024) void bn_bwd_final_kernel(const double* partia
     }
 }
 
-// grid * 256 is a multiple of 24, so a thread meets the same four channels at every stride: constants in registers
+// grid * 256 is a multiple of 24 (and of 12), so a thread meets the same channels at every stride: constants in registers
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ c, const T* __restrict__ dt,
                                                            const float* __restrict__ slope, const float* __restrict__ coef,
-                                                           float dscale, T* __restrict__ dc, size_t n4, float* amax)
+                                                           float dscale, T* __restrict__ dc, size_t nvec, float* amax)
 {
+    constexpr int V = StoreVec<T>::N, CPP = 96 / V;
     const size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x;
     float m = 0.f;
-    const int ch = (int)(i0 % 24) * 4;
-    float A[4], B[4], C[4], P[4], Q[4], S[4];
+    const int ch = (int)(i0 % CPP) * V;
+    float A[V], B[V], C[V], P[V], Q[V], S[V];
+    ldf<V>(coef + ch, A);
+    ldf<V>(coef + 96 + ch, B);
+    ldf<V>(coef + 192 + ch, C);
+    ldf<V>(coef + 288 + ch, P);
+    ldf<V>(coef + 384 + ch, Q);
+    if (slope) ldf<V>(slope + ch, S);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        A[e] = coef[ch + e] * dscale; B[e] = coef[96 + ch + e]; C[e] = coef[192 + ch + e];
-        P[e] = coef[288 + ch + e]; Q[e] = coef[384 + ch + e];
-        S[e] = slope ? slope[ch + e] : 1.f;
+    for (int e = 0; e < V; ++e) {
+        A[e] *= dscale;
+        if (!slope) S[e] = 1.f;
     }
-    for (size_t i = i0; i < n4; i += (size_t)gridDim.x * 256) {
-        float cv[4], dv[4], o[4];
-        ld4(c + i * 4, cv);
-        ld4(dt + i * 4, dv);
+    for (size_t i = i0; i < nvec; i += (size_t)gridDim.x * 256) {
+        float cv[V], dv[V], o[V];
+        ldv(c + i * V, cv);
+        ldv(dt + i * V, dv);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < V; ++e) {
             const float z = fmaf(cv[e], P[e], Q[e]);
             const float dz = (slope && z < 0.f) ? dv[e] * S[e] : dv[e];
             o[e] = fmaf(A[e], dz, -C[e]) - B[e] * cv[e];
             m = fmaxf(m, fabsf(o[e]));
         }
-        st4(dc + i * 4, o);
+        stv(dc + i * V, o);
     }
     // max |dc| for the split-f16 data-gradient conv that reads dc next (its in_amax): slot = workgroup mod kAmaxSlots,
     // zeroed by bn_bwd_final_kernel; non-negative floats order like their bit patterns
@@ -956,15 +966,17 @@ static hipError_t bn_train_bwd_t(const T* c, const T* dt, const float* stats, co
     static_assert(kAmaxSlots == 1024, "bn_bwd_final_kernel zeroes one slot per thread");
     double* partial = (double*)scratch;
     float* coef = (float*)(partial + (size_t)BNB_BLOCKS * 288);
-    const int nb = npix < (size_t)BNB_BLOCKS * 10 ? (int)((npix + 9) / 10) : BNB_BLOCKS;
+    constexpr int ROWS = BNB_THREADS / (96 / StoreVec<T>::N);
+    const int nb = npix < (size_t)BNB_BLOCKS * ROWS ? (int)((npix + ROWS - 1) / ROWS) : BNB_BLOCKS;
     hipLaunchKernelGGL(bn_bwd_stats_kernel<T>, dim3(nb), dim3(256), 0, s, c, dt, stats, gamma, beta, slope, dscale, npix, partial);
     hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(8), dim3(1024), 0, s, partial, nb, (double)npix, stats, gamma, beta, coef, dgamma,
                        dbeta, dslope, dc_amax);
-    const size_t n4 = npix * 24;
-    size_t want = (n4 + 255) / 256;
-    if (want > 6144) want = 6144;
+    const size_t nvec = npix * (96 / StoreVec<T>::N);
+    size_t want = (nvec + 255) / 256;
+    const size_t cap = 6144 * 4 / StoreVec<T>::N;                // (the per-thread constants are loaded once: >= 4 units each)
+    if (want > cap) want = cap;
     want = (want + 2) / 3 * 3;                                   // (grid * 256) % 24 == 0
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3((unsigned)want), dim3(256), 0, s, c, dt, slope, coef, dscale, dc, n4, dc_amax);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3((unsigned)want), dim3(256), 0, s, c, dt, slope, coef, dscale, dc, nvec, dc_amax);
     return hipGetLastError();
 }
 
@@ -1163,15 +1175,16 @@ hipError_t launch_adamw(float* p, const float* g, float* m, float* v, size_t n, 
 // ---- scalar-slope PReLU (Generator.py:51, 9, 70), elementwise over any fp32 tensor -----------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void prelu_scalar_fwd_kernel(const T* __restrict__ x, const float* __restrict__ slope,
-                                                               T* __restrict__ y, size_t n4)
+                                                               T* __restrict__ y, size_t nvec)
 {
+    constexpr int V = StoreVec<T>::N;
     const float a = slope[0];
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-        float v[4];
-        ld4(x + i * 4, v);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
+        float v[V];
+        ldv(x + i * V, v);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.f ? v[e] : v[e] * a;
-        st4(y + i * 4, v);
+        for (int e = 0; e < V; ++e) v[e] = v[e] >= 0.f ? v[e] : v[e] * a;
+        stv(y + i * V, v);
     }
 }
 
@@ -1180,25 +1193,26 @@ __global__ __launch_bounds__(256) void prelu_scalar_fwd_kernel(const T* __restri
 template <typename T>
 __global__ __launch_bounds__(256) void prelu_scalar_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                                const T* __restrict__ dy2, const float* __restrict__ slope,
-                                                               T* __restrict__ dx, size_t n4, double* __restrict__ partial)
+                                                               T* __restrict__ dx, size_t nvec, double* __restrict__ partial)
 {
+    constexpr int V = StoreVec<T>::N;
     __shared__ double red[256];
     const float a = slope[0];
     float acc = 0.f;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-        float v[4], d[4];
-        ld4(x + i * 4, v);
-        ld4(dy + i * 4, d);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
+        float v[V], d[V];
+        ldv(x + i * V, v);
+        ldv(dy + i * V, d);
         if (dy2) {
-            float d2[4];
-            ld4(dy2 + i * 4, d2);
+            float d2[V];
+            ldv(dy2 + i * V, d2);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) d[e] += d2[e];
+            for (int e = 0; e < V; ++e) d[e] += d2[e];
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+        for (int e = 0; e < V; ++e)
             if (v[e] < 0.f) { acc += d[e] * v[e]; d[e] *= a; }
-        st4(dx + i * 4, d);
+        stv(dx + i * V, d);
     }
     red[threadIdx.x] = (double)acc;
     __syncthreads();
@@ -1229,7 +1243,7 @@ size_t prelu_scratch_bytes() { return PRELU_BLOCKS * sizeof(double); }
 template <typename T>
 static hipError_t prelu_fwd_t(const T* x, const float* slope, T* y, size_t numel, hipStream_t s)
 {
-    const size_t n4 = numel / 4;
+    const size_t n4 = numel / StoreVec<T>::N;
     size_t nb = (n4 + 255) / 256;
     if (nb > 16384) nb = 16384;
     hipLaunchKernelGGL(prelu_scalar_fwd_kernel<T>, dim3((unsigned)nb), dim3(256), 0, s, x, slope, y, n4);
@@ -1240,7 +1254,7 @@ template <typename T>
 static hipError_t prelu_bwd_t(const T* x, const T* dy, const T* dy2, const float* slope, T* dx, float* dslope, size_t numel,
                               void* scratch, hipStream_t s)
 {
-    const size_t n4 = numel / 4;
+    const size_t n4 = numel / StoreVec<T>::N;
     size_t nb = (n4 + 255) / 256;
     if (nb > PRELU_BLOCKS) nb = PRELU_BLOCKS;
     hipLaunchKernelGGL(prelu_scalar_bwd_kernel<T>, dim3((unsigned)nb), dim3(256), 0, s, x, dy, dy2, slope, dx, n4, (double*)scratch);
@@ -1504,26 +1518,29 @@ template <typename T>
 __global__ __launch_bounds__(256) void ca_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy, int hw,
                                                             int parts, float* __restrict__ ds_partial)
 {
-    __shared__ float red[10][96];
+    constexpr int V = StoreVec<T>::N, CPP = 96 / V, ROWS = 240 / CPP;
+    __shared__ float red[ROWS][96];
     const int tid = threadIdx.x;
     const int per = hw / parts;
     const size_t p0 = (size_t)blockIdx.x * per;                   // blockIdx.x = image * parts + part
     if (tid < 240) {
-        const int c4 = tid % 24, row = tid / 24;
-        float s[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int p = row; p < per; p += 10) {
-            float v[4], d[4];
-            ld4(x + (p0 + p) * 96 + c4 * 4, v);
-            ld4(dy + (p0 + p) * 96 + c4 * 4, d);
+        const int cg = tid % CPP, row = tid / CPP;
+        float s[V];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) s[e] += v[e] * d[e];
+        for (int e = 0; e < V; ++e) s[e] = 0.f;
+        for (int p = row; p < per; p += ROWS) {
+            float v[V], d[V];
+            ldv(x + (p0 + p) * 96 + cg * V, v);
+            ldv(dy + (p0 + p) * 96 + cg * V, d);
+#pragma unroll
+            for (int e = 0; e < V; ++e) s[e] += v[e] * d[e];
         }
-        for (int e = 0; e < 4; ++e) red[row][c4 * 4 + e] = s[e];
+        for (int e = 0; e < V; ++e) red[row][cg * V + e] = s[e];
     }
     __syncthreads();
     if (tid < 96) {
         float a = 0.f;
-        for (int r = 0; r < 10; ++r) a += red[r][tid];
+        for (int r = 0; r < ROWS; ++r) a += red[r][tid];
         ds_partial[(size_t)blockIdx.x * 96 + tid] = a;
     }
 }
@@ -1597,19 +1614,20 @@ __global__ __launch_bounds__(256) void ca_bwd_wgrad_kernel(const float* __restri
 
 template <typename T>
 __global__ __launch_bounds__(256) void ca_bwd_apply_kernel(const T* __restrict__ dy, const float* __restrict__ scale,
-                                                           const float* __restrict__ dpool, int hw, T* __restrict__ dx, size_t n4)
+                                                           const float* __restrict__ dpool, int hw, T* __restrict__ dx, size_t nvec)
 {
+    constexpr int V = StoreVec<T>::N, CPP = 96 / V;
     const float inv = 1.f / (float)hw;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-        const int c = (int)(i % 24) * 4;
-        const size_t img = i / ((size_t)hw * 24);
-        float d[4];
-        ld4(dy + i * 4, d);
-        const f32x4 sc = *(const f32x4*)(scale + img * 96 + c);
-        const f32x4 dp = *(const f32x4*)(dpool + img * 96 + c);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % CPP) * V;
+        const size_t img = i / ((size_t)hw * CPP);
+        float d[V], sc[V], dp[V];
+        ldv(dy + i * V, d);
+        ldf<V>(scale + img * 96 + c, sc);
+        ldf<V>(dpool + img * 96 + c, dp);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) d[e] = fmaf(d[e], sc[e], dp[e] * inv);
-        st4(dx + i * 4, d);
+        for (int e = 0; e < V; ++e) d[e] = fmaf(d[e], sc[e], dp[e] * inv);
+        stv(dx + i * V, d);
     }
 }
 
@@ -1626,7 +1644,7 @@ static hipError_t chan_attn_bwd_t(const T* x, const T* dy, const float* pool_par
     hipLaunchKernelGGL(ca_bwd_fc_kernel, dim3((unsigned)n), dim3(128), 0, s, pool_partial, ds_partial, parts, hw, w1, b1, w2, scale,
                        dpool, vec);
     hipLaunchKernelGGL(ca_bwd_wgrad_kernel, dim3(5), dim3(256), 0, s, vec, n, dw1, db1, dw2, db2);
-    const size_t n4 = (size_t)n * hw * 24;
+    const size_t n4 = (size_t)n * hw * (96 / StoreVec<T>::N);
     const size_t want = (n4 + 255) / 256;
     hipLaunchKernelGGL(ca_bwd_apply_kernel<T>, dim3((unsigned)(want < 16384 ? want : 16384)), dim3(256), 0, s, dy, scale, dpool, hw, dx, n4);
     return hipGetLastError();

@@ -89,8 +89,9 @@ class Generator(nn.Module):
         self._weights_sig: Dict[int, Tuple] = {}       # device index -> signature of uploaded weights
         self._workspace: Dict[Tuple[int, int], torch.Tensor] = {}
         self._engines: Dict[int, object] = {}          # device index -> training.GeneratorGrad (train-mode operators)
-        # 3x3 conv products of the train-mode forward / backward: "auto" = f16 products inside torch.autocast with a
-        # 16-bit dtype (how train.py:91,148,166 call the generator), fp32 products otherwise; or "fp32" / "f16"
+        # arithmetic of the train-mode forward / backward: "auto" = that of the autocast dtype inside torch.autocast ("bf16":
+        # bf16 tensors and products, how train.py:91,148,166 call the generator; "f16" for float16), fp32 otherwise; or one
+        # of "fp32" / "f16" (fp32 tensors, 16-bit conv products) / "bf16" (training.conv_precision)
         self.train_precision = "auto"
 
     # ---- HIP handle / weights ----------------------------------------------------------
@@ -198,17 +199,18 @@ class Generator(nn.Module):
         train.py:92,149,167): batch-statistics BatchNorm from the LIVE parameters (weight images are made on the device, so
         an optimizer step costs no host re-upload), running statistics updated as ``nn.BatchNorm2d`` does.  With gradient
         recording on, the result carries a graph whose backward is the HIP backward pass (``autograd.GeneratorTrainFn``).
-        Tensors are fp32; under ``torch.autocast(bfloat16)`` (or with a bf16 input) the 3x3 conv products are 16-bit
-        (``train_precision``) and the output is rounded to bf16 once, as the reference's autocast returns it."""
+        Under ``torch.autocast(bfloat16)`` (or with a bf16 input) the step runs on bf16 tensors with bf16 products
+        (``train_precision``; the output image is computed in fp32 and rounded to bf16 once, as the reference's autocast
+        returns it); otherwise tensors are fp32."""
         from . import autograd as A, training as T
         xc, code, dt = self._prepare(x)
         if xc.shape[0] == 0:
             raise ValueError("Expected more than 1 value per channel when training, got an empty batch")
         if self.train_precision not in ("auto", "fp32", "f16", "bf16"):
-            raise RuntimeError(f"train_precision '{self.train_precision}': expected auto, fp32 or f16")
+            raise RuntimeError(f"train_precision '{self.train_precision}': expected auto, fp32, f16 or bf16")
         precision = T.resolve_precision(self.train_precision)
         if self.train_precision == "auto" and code != _lib.SRGEN_F32 and T.conv_path() == "split":
-            precision = "f16"                                  # a bf16 input outside autocast: same 16-bit arithmetic
+            precision = "bf16"                                 # a bf16 input outside autocast: same 16-bit arithmetic
         engine = self._engine(xc.device)
         with torch.cuda.device(xc.device):
             if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):

@@ -187,13 +187,17 @@ def conv_precision(precision: str):
 
 
 def resolve_precision(precision: str) -> str:
-    """``"auto"`` -> "f16" when the caller is inside ``torch.autocast`` for ROCm devices with a 16-bit dtype (the way the
-    reference runs its training forward, train.py:91) and the split path is active, else "fp32"."""
+    """``"auto"``: inside ``torch.autocast`` for ROCm devices (the way the reference runs its training forward, train.py:91)
+    the 16-bit arithmetic of the autocast dtype -- "bf16" (bf16 tensors and products: what autocast(bfloat16) itself
+    computes) or, for float16, "f16" (f16 products on fp32 tensors) -- when the split path is active; else "fp32"."""
     if precision != "auto":
         return precision
-    if torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") in (torch.bfloat16, torch.float16) \
-            and conv_path() == "split":
-        return "f16"
+    if torch.is_autocast_enabled("cuda") and conv_path() == "split":
+        dt = torch.get_autocast_dtype("cuda")
+        if dt == torch.bfloat16:
+            return "bf16"
+        if dt == torch.float16:
+            return "f16"
     return "fp32"
 
 
@@ -1011,8 +1015,9 @@ class PretrainStep(GeneratorGrad):
     BatchNorm running statistics are updated as ``nn.BatchNorm2d`` does.  ``precision`` picks the arithmetic: "fp32"
     (fp32 tensors, fp32-accurate 3x3 conv products), "f16" (fp32 tensors, 16-bit operands in the 3x3 convs, fp32
     accumulation), "bf16" (the 16-bit step: bf16 activation and gradient tensors, bf16 products, fp32 accumulation -- the
-    storage and product types of the reference's own autocast step) or "auto" (default: "f16" when ``step`` is called inside ``torch.autocast`` with a 16-bit dtype, as train.py:91
-    calls the generator, else "fp32"; see ``conv_precision``).  With
+    storage and product types of the reference's own autocast step) or "auto" (default: the autocast dtype's arithmetic --
+    "bf16" inside ``torch.autocast(dtype=torch.bfloat16)``, as train.py:91 calls the generator, "f16" inside float16 autocast, else
+    "fp32"; see ``resolve_precision``).  With
     ``world_size > 1`` (one process per GPU, ``torch.distributed`` initialised) ``step`` averages ``flat_grad`` over the
     ranks with one all-reduce before the update, as DistributedDataParallel would."""
 

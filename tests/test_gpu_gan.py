@@ -286,17 +286,19 @@ def test_gan_steps_run_and_skip_discriminator_update():
     assert not all(torch.equal(a, b.detach()) for a, b in zip(before, d.parameters()))
 
 
-def test_gan_step_f16_products_stays_close_to_the_fp32_step():
-    """GanStep(precision="f16") -- and "auto" inside torch.autocast, the way train.py:148-149,166-167 run the generator --
-    against the fp32 iteration on the same inputs: losses within 1e-3, the flat generator gradient within 2 % in the
-    2-norm (cosine > 0.9998), and not identical (the switch reaches the generator's convs through GanStep)."""
+def test_gan_step_16_bit_arithmetics_stay_close_to_the_fp32_step():
+    """GanStep(precision="f16" | "bf16") -- and "auto" inside torch.autocast, the way train.py:148-149,166-167 run the
+    generator (bfloat16 -> the bf16 step, float16 -> f16 products) -- against the fp32 iteration on the same inputs: losses
+    within 1e-3 (f16) / 5e-3 (bf16), the flat generator gradient within 2 % / 8 % in the 2-norm (cosine > 0.9998 / 0.997: what
+    11 and 8 significant bits leave), and not identical (the switch reaches the generator's kernels through GanStep)."""
     ref = None
-    for mode in ("fp32", "f16", "auto"):
+    bars = {"f16": (1e-3, 2e-2, 0.9998), "bf16": (5e-3, 8e-2, 0.997)}
+    for mode, ac in (("fp32", None), ("f16", None), ("auto", torch.float16), ("bf16", None), ("auto", torch.bfloat16)):
         g, d, _, lr, hr = _gan_setup()
         from superresolution_amd.gan_training import GanStep
         step = GanStep(g, d, precision=mode)
-        if mode == "auto":
-            with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+        if ac is not None:
+            with torch.autocast(device_type="cuda", dtype=ac):
                 out = step.step(lr, hr, update_d=True)
         else:
             out = step.step(lr, hr, update_d=True)
@@ -305,12 +307,14 @@ def test_gan_step_f16_products_stays_close_to_the_fp32_step():
         if mode == "fp32":
             ref = res
             continue
+        arith = mode if ac is None else ("bf16" if ac == torch.bfloat16 else "f16")
+        loss_tol, rel_tol, cos_min = bars[arith]
         for k, v in res[0].items():
-            assert abs(v - ref[0][k]) <= 1e-3 * max(abs(ref[0][k]), 1e-3), (mode, k, v, ref[0][k])
+            assert abs(v - ref[0][k]) <= loss_tol * max(abs(ref[0][k]), 1e-3), (mode, k, v, ref[0][k])
         rel = float((res[1] - ref[1]).norm() / ref[1].norm())
         cos = float(res[1] @ ref[1] / (res[1].norm() * ref[1].norm()))
-        print(f"GAN iteration, {mode}: flat generator gradient vs fp32: rel {rel:.2e}, cosine {cos:.6f}")
-        assert 1e-5 <= rel <= 2e-2 and cos >= 0.9998, (mode, rel, cos)
+        print(f"GAN iteration, {mode} ({arith}): flat generator gradient vs fp32: rel {rel:.2e}, cosine {cos:.6f}")
+        assert 1e-5 <= rel <= rel_tol and cos >= cos_min, (mode, rel, cos)
 
 
 def test_gan_step_reusing_the_forward_is_bit_identical():

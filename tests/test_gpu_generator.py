@@ -486,8 +486,8 @@ def test_eval_forward_is_detached_and_refuses_input_grad(gen, golden_inputs):
 
 def test_train_mode_forward_under_bf16_autocast():
     """The reference's train-mode call sites run under torch.autocast(bfloat16) (train.py:91-92,148-149,166-167).
-    Here the training operators run with 16-bit (f16) conv products on fp32 tensors and the result is rounded to bf16 once
-    (generator.py:_run_train_ops); checked against the reference's fp32
+    Here the training operators run the 16-bit step (bf16 tensors and products, fp32 accumulation: training.conv_precision
+    "bf16") and the image is rounded to bf16 once (generator.py:_run_train_ops); checked against the reference's fp32
     train-mode output (generator_train.npz y1) with the north_star bf16 bar (|dPSNR vs hr| <= 0.05 dB) and against
     the error the reference's own bf16 autocast makes (generator_train_bf16.npz, CPU autocast of the real reference)."""
     import os
@@ -510,9 +510,10 @@ def test_train_mode_forward_under_bf16_autocast():
     keys = [str(k) for k in gt["bn_keys"]]
     assert all(sd[k + ".running_mean"].dtype == torch.float32 for k in keys)
     em = max(np.abs(sd[k + ".running_mean"].cpu().numpy() - gt["mean1"][i]).max() for i, k in enumerate(keys))
-    # statistics are kept in fp32; their values carry the 16-bit conv products of the autocast call (f16 operands here:
-    # measured 1.6e-5; the reference's bf16 operands move them by ~1e-3), against 1e-5 for the fp32 call above
-    assert em <= 1e-4
+    # statistics are kept in fp32; their values carry the bf16 tensors and products of the autocast call (the reference's own
+    # autocast moves them by ~1e-3 too), against 1e-5 for the fp32 call above
+    print("running_mean error under bf16 autocast", em)
+    assert em <= 5e-3
     with torch.no_grad():
         yb2 = g(x.to(torch.bfloat16))                                    # bf16 input without autocast
     assert yb2.dtype == torch.bfloat16

@@ -553,8 +553,7 @@ def _sample_rel(a, b):
 
 
 def test_pretrain_step_f16_products_vs_reference_fp32_and_autocast_golden():
-    """The pre-train step with f16 conv products (precision="f16", and "auto" inside torch.autocast as train.py:91 calls
-    it) against ONE step of the real reference run both ways (make_golden_bwd.py step / step_autocast): every sampled
+    """The pre-train step with f16 conv products (precision="f16", and "auto" inside torch.autocast(float16)) against ONE step of the real reference run both ways (make_golden_bwd.py step / step_autocast): every sampled
     gradient is closer to the reference's fp32 gradient than the reference's own bf16-autocast gradient is (every one of the
     sixteen sampled tensors; by 2x at the median), the loss likewise."""
     from superresolution_amd import Generator, training as T, weights as W
@@ -569,6 +568,8 @@ def test_pretrain_step_f16_products_vs_reference_fp32_and_autocast_golden():
         step = T.PretrainStep(g, lr=1e-4, precision=mode)
         if mode == "auto":
             with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+                assert T.resolve_precision("auto") == "bf16"             # (tests/test_gpu_training_bf16.py)
+            with torch.autocast(device_type="cuda", dtype=torch.float16):
                 assert T.resolve_precision("auto") == "f16"
                 loss = step.forward_backward(lr, hr)
             assert T.resolve_precision("auto") == "fp32"

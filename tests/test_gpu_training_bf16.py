@@ -180,6 +180,15 @@ def test_pretrain_step_bf16_vs_reference_fp32_and_autocast_golden():
     g = g.cuda().train()
     step = T.PretrainStep(g, lr=1e-4, precision="bf16")
     loss = float(step.forward_backward(lr, hr))
+    # "auto" inside bf16 autocast -- the way train.py:91 calls the generator -- runs the same arithmetic
+    g2 = Generator()
+    g2.load_state_dict(W.synthetic_state_dict(0))
+    g2 = g2.cuda().train()
+    step2 = T.PretrainStep(g2, lr=1e-4)
+    with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+        assert T.resolve_precision("auto") == "bf16"
+        assert float(step2.forward_backward(lr, hr)) == loss
+    assert all(torch.equal(a.grad, b.grad) for a, b in zip(g.parameters(), g2.parameters()))
     ref_loss, ac_loss = float(g32["loss"]), float(gac["loss"])
     print("loss: fp32 reference", ref_loss, "reference autocast", ac_loss, "this bf16 step", loss)
     assert abs(loss - ref_loss) <= 1.5 * abs(ac_loss - ref_loss) + 1e-5 * abs(ref_loss)
@@ -191,7 +200,8 @@ def test_pretrain_step_bf16_vs_reference_fp32_and_autocast_golden():
         v = P[k[len("grad_sample_"):]].grad.detach().flatten()[::7].cpu().numpy()
         ours, theirs = _sample_rel(v, g32[k]), _sample_rel(gac[k], g32[k])
         print(f"  {k}: this step {ours:.2e}, reference autocast {theirs:.2e}")
-        assert ours <= 1.5 * theirs and ours <= 6e-2, (k, ours, theirs)
+        # (a tensor of one or two values -- a scalar PReLU slope -- is one draw of the rounding noise, not a norm over many)
+        assert ours <= (1.5 if v.size > 4 else 3.0) * theirs and ours <= 6e-2, (k, ours, theirs)
         ratios.append(ours / theirs)
     print("  this step's deviation / the reference autocast's: median", float(np.median(ratios)), "max", max(ratios))
     assert float(np.median(ratios)) <= 1.0

@@ -1,13 +1,13 @@
 #!/bin/bash
-# GPU box: rocprofv3 kernel trace of the pre-train step (bench.py --workload cfg3), both conv arithmetics.
-# usage: bash tools/prof_cfg3.sh <tag>   -> gpurun_out/prof_cfg3_<tag>/{fp32,f16}_kernel_stats.csv + bench lines
+# GPU box: rocprofv3 kernel trace of the pre-train step (bench.py --workload cfg3), all three arithmetics (PRECS="bf16" for one).
+# usage: bash tools/prof_cfg3.sh <tag>   -> gpurun_out/prof_cfg3_<tag>/{fp32,f16,bf16}_kernel_stats.csv + bench lines
 set -e
 TAG=${1:-r03}
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_cfg3_$TAG
 rm -rf $OUT; mkdir -p $OUT
-for P in fp32 f16; do
+for P in ${PRECS:-fp32 f16 bf16}; do
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${P}_trace -- python3 bench.py --workload cfg3 --train-precision $P --steps 10 --warmup 3 --no-cpu-baseline > $OUT/${P}_trace.log 2>&1
   grep -h '^{"metric"' $OUT/${P}_trace.log > $OUT/${P}_bench_under_rocprof.json || true
   f=$(find $OUT/${P}_trace -name '*kernel_stats.csv' | head -1)
