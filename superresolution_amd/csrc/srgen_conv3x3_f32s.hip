@@ -51,6 +51,8 @@ constexpr int LDS_BYTES = POOL_OFF + 4 * 96 * 4;  // 73,152 (two workgroups per 
 constexpr int A_ITEMS = HH * HWP * 4;             // float4 pieces per chunk (1,584)
 constexpr int A_REGS = 7;                         // ceil(1584 / 256)
 constexpr int MAX_WGS = 512;
+constexpr int kSmallItems = 96;                   // fewer work items than this (x 3 co tiles: about one workgroup per CU) run the
+                                                  // small-batch kernel: up to 5 images at 64 x 64, 1 at 128 x 128
 
 struct Frags { h8 xh[2], xl[2], wh[3], wl[3]; };
 
@@ -474,11 +476,266 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32s_kernel(Conv3x3Args a, int
     }
 }
 
+// ---- small batches (train.py:31-54 runs 4 images; the reference's CPU case runs 16) ----------------------------------------
+// With fewer work items than compute units the persistent kernel above leaves most of the chip idle and every item waits
+// out its 18 weight-group fetches one after the other (a group's 54 MFMAs per wave cover a fetch only when a second
+// workgroup shares the CU).  Here a workgroup is ONE (work item, 32-channel output tile): three times the workgroups, a
+// third of the MFMAs each, and ALL 18 weight groups of its tile (108 KB) requested at once into LDS before the first
+// product -- one trip to L2 instead of eighteen -- and the pixel loads of all six chunks behind them (168 registers: one
+// wave per SIMD has them to spare), so the only memory latency a workgroup waits out is the first.  A tap's fragments are
+// read from LDS under the products of the tap before.  The products enter every accumulator in the order of the kernel above (chunk, kernel row,
+// tap; low x high, high x low, high x high), so an image's result does not depend on which kernel its batch size selects.
+constexpr int WS_BYTES = 3 * 2 * 64 * 16;             // one weight group of ONE co tile: 3 taps x {hi, lo} x 64 lanes x 16 B
+constexpr int S_W_OFF = A_BYTES;
+constexpr int S_POOL_OFF = S_W_OFF + 18 * WS_BYTES;
+constexpr int S_LDS_BYTES = S_POOL_OFF + 4 * 96 * 4;  // 143,808: one workgroup per CU
+
+template <int HW, bool SHUFFLE, bool POOL, bool RES>
+__global__ __launch_bounds__(256, 1) void conv3x3_f32s_small_kernel(Conv3x3Args a, int nitems)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, p = lane & 31;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int tiles_x = HW / TW, tiles_y = HW / TH, tiles_img = tiles_x * tiles_y;
+    constexpr int CB = SHUFFLE ? 4 : 1;
+    const bool act = a.slope != nullptr;
+    const int cot = (int)blockIdx.x % 3, it = (int)blockIdx.x / 3;
+    Item cur;
+    cur.cb = it % CB;
+    {
+        const int tile = it / CB;
+        cur.tx = tile % tiles_x;
+        cur.ty = (tile / tiles_x) % tiles_y;
+        cur.n = tile / tiles_img;
+    }
+    char* const ldsA = lds;
+    float* const ldsPool = (float*)(lds + S_POOL_OFF);
+
+    // scaling exponents: as the kernel above
+    const int kw = split_tail_exp((const char*)a.wpack + (size_t)CB * kSplitImageBytes, lane);
+    int kx = 0;
+    if (a.in_amax && a.in_amax_per_image == 0) {
+        const f32x4 q = *(const f32x4*)(a.in_amax + tid * 4);
+        float m = fmaxf(fmaxf(q.x, q.y), fmaxf(q.z, q.w));
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if (lane == 0) ldsPool[w] = m;
+        __syncthreads();
+        kx = __builtin_amdgcn_readfirstlane(split_exp(fmaxf(fmaxf(ldsPool[0], ldsPool[1]), fmaxf(ldsPool[2], ldsPool[3]))));
+        __syncthreads();
+    } else if (a.in_amax) {
+        kx = __builtin_amdgcn_readfirstlane(split_exp(a.in_amax[cur.n]));
+    }
+    if (a.zero_amax && blockIdx.x == 0)
+        for (int i = tid; i < a.N; i += 256) a.zero_amax[i] = 0.f;
+
+    // ---- every weight group of this co tile: 18 groups x 6 pieces of 1 KB, wave w takes pieces w, w + 4, ... of the 108 ----
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+    {
+        const char* src = (const char*)a.wpack + (size_t)cur.cb * 18 * WG_BYTES;
+#pragma unroll
+        for (int k = 0; k < 27; ++k) {
+            const int piece = w + 4 * k;                         // = g * 6 + tap * 2 + hl
+            const int g = piece / 6, r = piece - g * 6, tap = r >> 1, hl = r & 1;
+            const unsigned goff = (unsigned)(g * WG_BYTES + ((tap * 3 + cot) * 2 + hl) * 1024 + lane * 16);
+            const unsigned la = lds_base + S_W_OFF + piece * 1024;
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                         :: "v"(goff), "s"(src), "s"(la) : "memory", "m0");
+        }
+    }
+
+    // ---- pixel staging (as above): fp32 pieces -> registers -> (hi, lo) -> LDS ----
+    f32x4 stage[NCH][A_REGS];
+    int aoff[A_REGS];
+    unsigned aok = 0;
+    {
+        const int x0 = cur.tx * TW, y0 = cur.ty * TH;
+#pragma unroll
+        for (int i7 = 0; i7 < A_REGS; ++i7) {
+            const int i = min(tid + i7 * 256, A_ITEMS - 1);
+            const int pix = i >> 2, q = i & 3;
+            const int r = pix / HWP, cc = pix - r * HWP;
+            const int gy = y0 - 1 + r, gx = x0 - 1 + cc;
+            const bool ok = (unsigned)gy < (unsigned)HW && (unsigned)gx < (unsigned)HW;
+            const int cy = min(max(gy, 0), HW - 1), cx = min(max(gx, 0), HW - 1);
+            aoff[i7] = (cy * HW + cx) * kC + q * 4;
+            aok |= (ok ? 1u : 0u) << i7;
+        }
+    }
+    const float* in = (const float*)a.in + (size_t)cur.n * HW * HW * kC;
+    auto load_a = [&](int c) {
+#pragma unroll
+        for (int i7 = 0; i7 < A_REGS; ++i7) stage[c][i7] = *(const f32x4*)(in + c * CK + aoff[i7]);
+    };
+    auto split_store_a = [&](int c) {
+#pragma unroll
+        for (int i7 = 0; i7 < A_REGS; ++i7) {
+            const float m = ((aok >> i7) & 1u) ? pow2f(kx) : 0.f;
+            unsigned h01, h23, l01, l23;
+            const f32x4 v = stage[c][i7];
+            asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=&v"(h01) : "v"(v.x), "v"(m));
+            asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h01) : "v"(v.y), "v"(m));
+            asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=&v"(h23) : "v"(v.z), "v"(m));
+            asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h23) : "v"(v.w), "v"(m));
+            asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=&v"(l01) : "v"(v.x), "v"(m), "v"(h01));
+            asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l01) : "v"(v.y), "v"(m), "v"(h01));
+            asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=&v"(l23) : "v"(v.z), "v"(m), "v"(h23));
+            asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l23) : "v"(v.w), "v"(m), "v"(h23));
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            const int i = tid + i7 * 256;
+            if (i7 < A_REGS - 1 || i < A_ITEMS) {
+                char* rec = ldsA + (i >> 2) * PSB + (i & 3) * 8;
+                *(u32x2*)rec = u32x2{h01, h23};
+                *(u32x2*)(rec + 32) = u32x2{l01, l23};
+            }
+        }
+    };
+
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) load_a(c);
+    // accumulators start at the (scaled) bias
+    const float acc_mul = pow2f(kw + kx), out_mul = pow2f(-(kw + kx));
+    f32x16 acc[2];
+#pragma unroll
+    for (int G = 0; G < 4; ++G) {
+        const f32x4 b4 = *(const f32x4*)(a.bias + cur.cb * 96 + 32 * cot + 8 * G + 4 * h) * acc_mul;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[0][4 * G + e] = acc[1][4 * G + e] = b4[e];
+    }
+    split_store_a(0);
+    // LDS-only barrier (__syncthreads() would also wait for the pixel loads that are meant to stay in flight)
+    auto lds_barrier = [&]() {
+        __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    const char* const Ax = ldsA + (w * HWP + p) * PSB + 16 * h;
+    const char* const Wl = lds + S_W_OFF + lane * 16;
+    struct SFrags { h8 wh, wl, xh[2], xl[2]; };
+    auto load_sfrags = [&](SFrags& f, int c, int tap) {
+        const int ky = tap / 3, kxx = tap - 3 * ky;
+        const char* ab = Ax + (ky * HWP + kxx) * PSB;
+        const char* wb = Wl + ((c * 3 + ky) * 6 + kxx * 2) * 1024;
+        f.wh = *(const h8*)wb;
+        f.wl = *(const h8*)(wb + 1024);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            f.xh[mt] = *(const h8*)(ab + mt * 32 * PSB);
+            f.xl[mt] = *(const h8*)(ab + mt * 32 * PSB + 32);
+        }
+    };
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        // chunk c's pixels are in LDS; for c = 0 every weight copy of this wave has to have landed too: the copies are the
+        // oldest vector-memory operations of the wave and return in order, so vmcnt(35) -- everything but the pixel loads of
+        // chunks 1 .. 5 -- covers them
+        if (c == 0) __builtin_amdgcn_s_waitcnt(0x8F73);
+        lds_barrier();
+        SFrags f[2];
+        load_sfrags(f[0], c, 0);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap + 1 < 9) load_sfrags(f[(tap + 1) & 1], c, tap + 1);
+            const SFrags& g = f[tap & 1];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                acc[mt] = MFMA_H(g.wl, g.xh[mt], acc[mt]);
+                acc[mt] = MFMA_H(g.wh, g.xl[mt], acc[mt]);
+                acc[mt] = MFMA_H(g.wh, g.xh[mt], acc[mt]);
+            }
+        }
+        if (c + 1 < NCH) {
+            lds_barrier();                                       // every wave is past its reads of chunk c
+            split_store_a(c + 1);
+        }
+    }
+
+    // ---- epilogue (as above, for this workgroup's co tile) ----
+    const int y = cur.ty * TH + w, x0 = cur.tx * TW;
+    float* out = (float*)a.out;
+    constexpr int PXS = SHUFFLE ? 2 * kC : kC;
+    if (SHUFFLE)
+        out += (((size_t)cur.n * 2 * HW + 2 * y + (cur.cb >> 1)) * 2 * HW + 2 * (x0 + p) + (cur.cb & 1)) * kC + 4 * h;
+    else
+        out += (((size_t)cur.n * HW + y) * HW + x0 + p) * kC + 4 * h;
+    const float* res = nullptr;
+    if (RES) res = (const float*)a.res + (((size_t)cur.n * HW + y) * HW + x0 + p) * kC + 4 * h + 32 * cot;
+    float vmax = 0.f;
+    float psum[16];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+        for (int G = 0; G < 4; ++G) {
+            f32x4 v = {acc[mt][4 * G], acc[mt][4 * G + 1], acc[mt][4 * G + 2], acc[mt][4 * G + 3]};
+            v *= out_mul;
+            if (act) {
+                const f32x4 s4 = *(const f32x4*)(a.slope + cur.cb * 96 + 32 * cot + 8 * G + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.f ? v[e] : v[e] * s4[e];
+            }
+            if (RES) v += *(const f32x4*)(res + (size_t)(32 * mt) * kC + 8 * G);
+            vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+            if (POOL) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) psum[4 * G + e] = mt == 0 ? v[e] : psum[4 * G + e] + v[e];
+            }
+            *(f32x4*)(out + (size_t)(32 * mt) * PXS + 32 * cot + 8 * G) = v;
+        }
+    }
+    if (POOL) {                                                   // this tile's 32 channel sums, in the order of the kernel above
+        float* P = ldsPool;
+        float (&t)[16] = psum;
+#pragma unroll
+        for (int k = 8, b = 1; k >= 1; k >>= 1, b <<= 1)
+#pragma unroll
+            for (int i = 0; i < k; ++i) {
+                const bool up = (lane & b) != 0;
+                const float send = up ? t[i] : t[i + k];
+                const float keep = up ? t[i + k] : t[i];
+                t[i] = keep + __shfl_xor(send, b);
+            }
+        t[0] += __shfl_xor(t[0], 16);
+        if ((lane & 16) == 0) {
+            const int q = 8 * (lane & 1) + 4 * ((lane >> 1) & 1) + 2 * ((lane >> 2) & 1) + ((lane >> 3) & 1);
+            P[w * 32 + (q & 3) + 8 * (q >> 2) + 4 * h] = t[0];
+        }
+        __syncthreads();
+        if (tid < 32) {
+            const float s = (P[tid] + P[32 + tid]) + (P[64 + tid] + P[96 + tid]);
+            a.pool_partial[((size_t)cur.n * tiles_img + cur.ty * tiles_x + cur.tx) * kC + 32 * cot + tid] = s;
+        }
+    }
+    if (a.out_amax) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+        if (lane == 0 && vmax == vmax) atomicMax((unsigned*)a.out_amax + cur.n, __float_as_uint(vmax));
+    }
+}
+
+template <int HW, bool SHUFFLE, bool POOL, bool RES>
+hipError_t launch_small(const Conv3x3Args& a, int nitems, hipStream_t s)
+{
+    static bool attr_set[64] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+        e = hipFuncSetAttribute((const void*)conv3x3_f32s_small_kernel<HW, SHUFFLE, POOL, RES>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES);
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL((conv3x3_f32s_small_kernel<HW, SHUFFLE, POOL, RES>), dim3((unsigned)(nitems * 3)), dim3(256), S_LDS_BYTES,
+                       s, a, nitems);
+    return hipGetLastError();
+}
+
 template <int HW, bool SHUFFLE, bool POOL, bool RES>
 hipError_t launch_one(const Conv3x3Args& a, hipStream_t s)
 {
     const int nitems = a.N * (HW / TH) * (HW / TW) * (SHUFFLE ? 4 : 1);     // multiple of 16
     const int grid = nitems < MAX_WGS ? nitems & ~7 : MAX_WGS;
+    if (a.terms == 3 && nitems < kSmallItems) return launch_small<HW, SHUFFLE, POOL, RES>(a, nitems, s);
     if (a.terms == 1) {
         if (POOL) return hipErrorInvalidValue;        // the f16-product variant serves the training operators only
         hipLaunchKernelGGL((conv3x3_f32s_kernel<HW, SHUFFLE, false, RES, 0, 1>), dim3((unsigned)grid), dim3(256), LDS_BYTES,

@@ -240,10 +240,12 @@ def test_bf16_layer_taps(gen, golden, golden_inputs):
 # ---- batch shapes: the conv kernels are persistent (workgroups walk a per-XCD range of tiles),
 # ---- so ragged / small / full batches exercise different grid shapes and item walks -----------
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("n", [1, 3, 5, 37])
+@pytest.mark.parametrize("n", [1, 3, 5, 6, 37])
 def test_ragged_batches_are_image_independent(gen, n, dtype):
     """Eval-mode images are independent (BN running stats, per-image pool): image i of a ragged
-    batch must equal the same image run alone, bit for bit (same tiles, same arithmetic order)."""
+    batch must equal the same image run alone, bit for bit (same tiles, same arithmetic order) -- also across the fp32
+    path's two 3x3 kernels: up to 5 images run the small-batch kernel (one output-channel tile per workgroup), 6 and more
+    the persistent one, and both add an output's products in the same order."""
     from superresolution_amd import weights as W
     x = torch.from_numpy(W.synthetic_lr_batch(n, seed=11, kind="dense")).cuda().to(dtype)
     y = gen(x)
