@@ -143,6 +143,11 @@ def lib() -> ctypes.CDLL:
     L.srdisc_stem_dgrad.argtypes = [vp, vp, i, i, i, vp, vp]
     L.srdisc_tail_bwd.argtypes = [vp, vp, vp, i, i, i, i, f, vp, vp, vp, vp]
     L.srgen_ragan_loss_grad.argtypes = [vp, vp, sz, sz, f, f, f, vp, vp, vp]
+    L.srdisc_pack_bf16.argtypes = L.srdisc_pack.argtypes
+    L.srdisc_conv_nhwc_bf16p.argtypes = L.srdisc_conv_nhwc.argtypes
+    L.srdisc_conv_dgrad2_bf16p.argtypes = L.srdisc_conv_dgrad2.argtypes
+    for name in ("srdisc_pack_bf16", "srdisc_conv_nhwc_bf16p", "srdisc_conv_dgrad2_bf16p"):
+        getattr(L, name).restype = i
     L.srgen_clip_grad_norm_scratch_bytes.argtypes = [psz]
     L.srgen_clip_grad_norm.argtypes = [vp, sz, f, vp, vp, sz, vp]
     for name in ("srdisc_pack", "srdisc_stem_nhwc", "srdisc_conv_nhwc", "srdisc_tail",

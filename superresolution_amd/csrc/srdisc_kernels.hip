@@ -16,6 +16,8 @@
 //   ragan_loss_kernel  both losses of RelativisticAverageLoss in one single-workgroup launch.
 #include "srgen_internal.h"
 
+#include <type_traits>
+
 #include <cstdlib>
 
 namespace srgen {
@@ -128,17 +130,26 @@ struct ConvTile {
     int p[G];                   // output pixel of each 16-pixel group (may lie past M)
     unsigned vmask[G];          // bit t: tap t of that pixel lies inside the image (0 past M)
     const float* base[G];       // address of tap (0,0), channel 4*kq (may be out of image)
-    const f32x4* wp;            // this lane's weight fragments of the tile's 64-channel block
+    const char* wp;             // this lane's weight fragments of the tile's 64-channel block (16-byte fp32 or 8-byte bf16 units)
     int cb;
 };
 
 // PAR (stride-2 data gradient, one output parity class per launch; srdisc_train_kernels.hip): the conv runs over the
 // class grid OH x OW of the upper layer's dpre with the 1, 2 or 4 taps of a.taps (4-bit tap ids, real taps first, id 15 =
 // padding that reads zeros), and output pixel (oy, ox) of the class is pixel (2 oy + py, 2 ox + px) of the FH x FW image.
-template <int STRIDE, int G, bool PAR = false>
+//
+// BF (the GAN step's 16-bit arithmetic, train.py:148-150,166-168 under bf16 autocast): tensors stay fp32 in memory; a chunk's
+// activation fragment is rounded to bf16 when it is used and the weights come from a bf16 pack of the same layout (units
+// of four bf16), so a chunk is ONE v_mfma_f32_16x16x16_bf16 per accumulator instead of four v_mfma_f32_16x16x4_f32
+// (lane (l16, kq) supplies K = 4 kq .. 4 kq + 3 of the chunk either way), fp32 accumulation.
+template <int STRIDE, int G, bool PAR = false, bool BF = false>
 __global__ __launch_bounds__(256, G == 4 ? 1 : 2) void disc_conv_kernel(DiscConvArgs a, int OH, int OW, int M,
                                                                         int lg_nst, int ntiles)
 {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    using WFrag = std::conditional_t<BF, u32x2, f32x4>;
+    constexpr int WU = sizeof(WFrag);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int l16 = lane & 15, kq = lane >> 4;
     const int ncb = a.Cout >> 6;
@@ -168,7 +179,7 @@ __global__ __launch_bounds__(256, G == 4 ? 1 : 2) void disc_conv_kernel(DiscConv
             T.vmask[g] = m;
             T.base[g] = a.in + (((long long)img * a.H + iy0) * a.W + ix0) * a.Cin + kq * 4;
         }
-        T.wp = reinterpret_cast<const f32x4*>(a.wpack) + (size_t)T.cb * total * 1024 + lane;
+        T.wp = reinterpret_cast<const char*>(a.wpack) + ((size_t)T.cb * total * 1024 + lane) * WU;
     };
 
     const float* cur[G];                        // the activation pointers (chunk 0) of the step being loaded
@@ -184,14 +195,15 @@ __global__ __launch_bounds__(256, G == 4 ? 1 : 2) void disc_conv_kernel(DiscConv
     // other XCDs' traffic); weight fragments (L2-resident: an XCD sees one or two 64-channel blocks):
     // two buffers, one chunk ahead.  Weights are issued BEFORE the activations of the same slot: vmcnt
     // retires in order, so waiting for w(i) must not also wait for the younger x(i+2).
-    f32x4 xb[4][G], wb[2][4];
+    f32x4 xb[4][G];
+    WFrag wb[2][4];
     auto load_x = [&](int slot, int c) {
 #pragma unroll
         for (int g = 0; g < G; ++g) xb[slot][g] = *reinterpret_cast<const f32x4*>(cur[g] + c * 16);
     };
-    auto load_w = [&](int slot, const f32x4* wp, int st, int c) {
+    auto load_w = [&](int slot, const char* wp, int st, int c) {
         if (PAR && (st >> lg_nst) >= a.nreal) st &= nst - 1;     // a padding tap multiplies zeros: any real weights do
-        const f32x4* w = wp + ((size_t)st * 4 + c) * 256;
+        const WFrag* w = reinterpret_cast<const WFrag*>(wp) + ((size_t)st * 4 + c) * 256;
 #pragma unroll
         for (int s = 0; s < 4; ++s) wb[slot][s] = w[s * 64];
     };
@@ -204,13 +216,25 @@ __global__ __launch_bounds__(256, G == 4 ? 1 : 2) void disc_conv_kernel(DiscConv
             for (int g = 0; g < G; ++g) acc[s][g] = f32x4{0.f, 0.f, 0.f, 0.f};
     };
     auto mma = [&](int ws, int xs) {
+        if constexpr (BF) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+            for (int g = 0; g < G; ++g) {
+                const f32x4 x = xb[xs][g];
+                const u32x2 xp = {pack2_bf16(x[0], x[1]), pack2_bf16(x[2], x[3])};
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+                for (int s = 0; s < 4; ++s)
+                    acc[s][g] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, wb[ws][s]),
+                                                                          __builtin_bit_cast(s16x4, xp), acc[s][g], 0, 0, 0);
+            }
+        } else {
 #pragma unroll
-                for (int g = 0; g < G; ++g)
-                    acc[s][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[ws][s][j], xb[xs][g][j], acc[s][g], 0, 0, 0);
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int g = 0; g < G; ++g)
+                        acc[s][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[ws][s][j], xb[xs][g][j], acc[s][g], 0, 0, 0);
+        }
     };
 
     // One step = four chunks of tile T at step st; its prefetches reach into step sn of tile N (N is T
@@ -432,18 +456,18 @@ static hipError_t launch_conv_grid(const DiscConvArgs& a, int OH, int OW, long l
     const long long resident = (long long)cus * per_cu;
     const dim3 grid((unsigned)(blocks < resident ? blocks : resident)), block(256);
     const int ntiles = (int)blocks;
-    if (par && wide)
-        hipLaunchKernelGGL((disc_conv_kernel<1, 4, true>), grid, block, lds_pad, s, a, OH, OW, (int)M, lg, ntiles);
-    else if (par)
-        hipLaunchKernelGGL((disc_conv_kernel<1, 2, true>), grid, block, lds_pad, s, a, OH, OW, (int)M, lg, ntiles);
-    else if (a.stride == 1 && wide)
-        hipLaunchKernelGGL((disc_conv_kernel<1, 4>), grid, block, lds_pad, s, a, OH, OW, (int)M, lg, ntiles);
-    else if (a.stride == 1)
-        hipLaunchKernelGGL((disc_conv_kernel<1, 2>), grid, block, lds_pad, s, a, OH, OW, (int)M, lg, ntiles);
-    else if (wide)
-        hipLaunchKernelGGL((disc_conv_kernel<2, 4>), grid, block, lds_pad, s, a, OH, OW, (int)M, lg, ntiles);
-    else
-        hipLaunchKernelGGL((disc_conv_kernel<2, 2>), grid, block, lds_pad, s, a, OH, OW, (int)M, lg, ntiles);
+#define DISC_LAUNCH(ST, GG, PP)                                                                                          \
+    do {                                                                                                                 \
+        if (a.bf16) hipLaunchKernelGGL((disc_conv_kernel<ST, GG, PP, true>), grid, block, lds_pad, s, a, OH, OW, (int)M, lg, ntiles); \
+        else hipLaunchKernelGGL((disc_conv_kernel<ST, GG, PP, false>), grid, block, lds_pad, s, a, OH, OW, (int)M, lg, ntiles);       \
+    } while (0)
+    if (par && wide) DISC_LAUNCH(1, 4, true);
+    else if (par) DISC_LAUNCH(1, 2, true);
+    else if (a.stride == 1 && wide) DISC_LAUNCH(1, 4, false);
+    else if (a.stride == 1) DISC_LAUNCH(1, 2, false);
+    else if (wide) DISC_LAUNCH(2, 4, false);
+    else DISC_LAUNCH(2, 2, false);
+#undef DISC_LAUNCH
     return hipGetLastError();
 }
 
@@ -474,7 +498,7 @@ hipError_t launch_disc_dgrad2(const DiscConvArgs& a0, const float* wpack4, int f
         const int ntaps = (py + 1) * (px + 1);
         DiscConvArgs a = a0;
         a.stride = 1;
-        a.wpack = wpack4 + woff;
+        a.wpack = a0.bf16 ? (const float*)((const unsigned short*)wpack4 + woff) : wpack4 + woff;
         woff += (size_t)ntaps * a0.Cin * a0.Cout;
         const int CH = (fh - py + 1) / 2, CW = (fw - px + 1) / 2;           // rows / columns of that parity in the image
         if (CH <= 0 || CW <= 0) continue;

@@ -40,7 +40,20 @@ int check_channels(int cin, int cout)
 
 extern "C" {
 
+static int disc_pack_any(const float* w_oihw, int cin, int cout, int mode, void* out, void* stream, bool bf16);
+
 int srdisc_pack(const float* w_oihw, int cin, int cout, int mode, float* out, void* stream)
+{
+    return disc_pack_any(w_oihw, cin, cout, mode, out, stream, false);
+}
+
+int srdisc_pack_bf16(const float* w_oihw, int cin, int cout, int mode, void* out, void* stream)
+{
+    if (mode == 2 || mode == 3) return fail(SRGEN_E_UNSUPPORTED, "the stem and tail layers keep fp32 products: no bf16 pack (mode %d)", mode);
+    return disc_pack_any(w_oihw, cin, cout, mode, out, stream, true);
+}
+
+static int disc_pack_any(const float* w_oihw, int cin, int cout, int mode, void* out, void* stream, bool bf16)
 {
     if (!w_oihw || !out) return fail(SRGEN_E_INVALID, "NULL argument");
     if (mode < 0 || mode > 4)
@@ -48,7 +61,7 @@ int srdisc_pack(const float* w_oihw, int cin, int cout, int mode, float* out, vo
     if (mode <= 1 || mode == 4) { if (int rc = check_channels(mode ? cout : cin, mode ? cin : cout)) return rc; }
     else if (mode == 2 && (cin != 3 || cout != 64)) return fail(SRGEN_E_UNSUPPORTED, "stem pack is 3 -> 64");
     else if (mode == 3 && (cin % 4 || cout != 1)) return fail(SRGEN_E_UNSUPPORTED, "tail pack is cin -> 1, cin %% 4 == 0");
-    HIP_TRY(launch_disc_pack(w_oihw, out, cin, cout, mode, (hipStream_t)stream));
+    HIP_TRY(launch_disc_pack(w_oihw, (float*)out, cin, cout, mode, (hipStream_t)stream, bf16));
     return SRGEN_OK;
 }
 
@@ -63,8 +76,23 @@ int srdisc_stem_nhwc(const float* x_nchw, const float* wpack, const float* bias,
     return SRGEN_OK;
 }
 
+static int disc_conv_any(const float* in, const void* wpack, const float* bias, const float* mask, float* out, int n, int h, int w,
+                         int cin, int cout, int stride, float slope, void* stream, int bf16);
+
 int srdisc_conv_nhwc(const float* in, const float* wpack, const float* bias, const float* mask, float* out, int n, int h, int w,
                      int cin, int cout, int stride, float slope, void* stream)
+{
+    return disc_conv_any(in, wpack, bias, mask, out, n, h, w, cin, cout, stride, slope, stream, 0);
+}
+
+int srdisc_conv_nhwc_bf16p(const float* in, const void* wpack_bf16, const float* bias, const float* mask, float* out, int n, int h,
+                           int w, int cin, int cout, int stride, float slope, void* stream)
+{
+    return disc_conv_any(in, wpack_bf16, bias, mask, out, n, h, w, cin, cout, stride, slope, stream, 1);
+}
+
+static int disc_conv_any(const float* in, const void* wpack, const float* bias, const float* mask, float* out, int n, int h, int w,
+                         int cin, int cout, int stride, float slope, void* stream, int bf16)
 {
     if (!in || !wpack || !out || (!bias && !mask)) return fail(SRGEN_E_INVALID, "NULL argument (bias and mask cannot both be NULL)");
     if (int rc = check_img(n, h, w)) return rc;
@@ -74,14 +102,30 @@ int srdisc_conv_nhwc(const float* in, const float* wpack, const float* bias, con
         return fail(SRGEN_E_INVALID, "operands must be 16-byte aligned");
     const float* zeros = nullptr;
     if (int rc = train_zero_page(&zeros)) return rc;
-    DiscConvArgs a{in, out, wpack, bias, n, h, w, cin, cout, stride, slope, zeros};
+    DiscConvArgs a{in, out, (const float*)wpack, bias, n, h, w, cin, cout, stride, slope, zeros};
     a.mask = mask;
+    a.bf16 = bf16;
     HIP_TRY(launch_disc_conv(a, (hipStream_t)stream));
     return SRGEN_OK;
 }
 
+static int disc_dgrad2_any(const float* dpre, const void* wpack4, const float* mask, float* out, int n, int h, int w, int cin, int cout,
+                           float slope, void* stream, int bf16);
+
 int srdisc_conv_dgrad2(const float* dpre, const float* wpack4, const float* mask, float* out, int n, int h, int w, int cin, int cout,
                        float slope, void* stream)
+{
+    return disc_dgrad2_any(dpre, wpack4, mask, out, n, h, w, cin, cout, slope, stream, 0);
+}
+
+int srdisc_conv_dgrad2_bf16p(const float* dpre, const void* wpack4_bf16, const float* mask, float* out, int n, int h, int w, int cin,
+                             int cout, float slope, void* stream)
+{
+    return disc_dgrad2_any(dpre, wpack4_bf16, mask, out, n, h, w, cin, cout, slope, stream, 1);
+}
+
+static int disc_dgrad2_any(const float* dpre, const void* wpack4, const float* mask, float* out, int n, int h, int w, int cin, int cout,
+                           float slope, void* stream, int bf16)
 {
     if (!dpre || !wpack4 || !mask || !out) return fail(SRGEN_E_INVALID, "NULL argument");
     if (int rc = check_img(n, h, w)) return rc;
@@ -91,9 +135,10 @@ int srdisc_conv_dgrad2(const float* dpre, const float* wpack4, const float* mask
     const float* zeros = nullptr;
     if (int rc = train_zero_page(&zeros)) return rc;
     const int oh = (h - 1) / 2 + 1, ow = (w - 1) / 2 + 1;
-    DiscConvArgs a{dpre, out, wpack4, nullptr, n, oh, ow, cout, cin, 1, slope, zeros};
+    DiscConvArgs a{dpre, out, (const float*)wpack4, nullptr, n, oh, ow, cout, cin, 1, slope, zeros};
     a.mask = mask;
-    HIP_TRY(launch_disc_dgrad2(a, wpack4, h, w, (hipStream_t)stream));
+    a.bf16 = bf16;
+    HIP_TRY(launch_disc_dgrad2(a, (const float*)wpack4, h, w, (hipStream_t)stream));
     return SRGEN_OK;
 }
 

@@ -24,7 +24,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // ---- weight packs made on the device from the live OIHW parameters ----------------------------------------------
 // mode 0: forward pack of pack_disc_conv (srdisc_api.cpp): float4 units [cout/64][tap 9][cin/16][s 4][lane 64]
 // mode 1: the same layout for the data-gradient conv: cin' = cout, cout' = cin, w'[co'][ci'][tap] = w[ci'][co'][8 - tap]
-__global__ __launch_bounds__(256) void disc_pack_kernel(const float* __restrict__ w, float* __restrict__ out, int cin, int cout,
+// OutT = bf16_t: the same layout in bf16 (units of four = 8 bytes) for disc_conv_kernel<.., BF = true>
+__device__ __forceinline__ void put1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void put1(bf16_t* p, float v) { p->bits = (unsigned short)(pack2_bf16(v, 0.f) & 0xffffu); }
+
+template <typename OutT>
+__global__ __launch_bounds__(256) void disc_pack_kernel(const float* __restrict__ w, OutT* __restrict__ out, int cin, int cout,
                                                         int mode, size_t total)
 {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;           // one packed float
@@ -41,14 +46,15 @@ __global__ __launch_bounds__(256) void disc_pack_kernel(const float* __restrict_
     const int m = lane & 15, kq = lane >> 4;
     const int co = 64 * cb + 16 * (m >> 2) + 4 * s + (m & 3);
     const int ci = 16 * ch + 4 * kq + j;
-    out[idx] = mode ? w[((size_t)ci * cin + co) * 9 + (8 - tap)] : w[((size_t)co * cin + ci) * 9 + tap];
+    put1(out + idx, mode ? w[((size_t)ci * cin + co) * 9 + (8 - tap)] : w[((size_t)co * cin + ci) * 9 + tap]);
 }
 
 // Packs of a stride-2 layer's data gradient, one per output parity class (py, px) (disc_conv_kernel<.., PAR>): input
 // pixel y = 2a + py receives dpre[a + dy] * w[ky] with ky = py + 1 - 2 dy, dy in {0} (py = 0) or {0, 1} (py = 1), and the
 // same along x: 1, 2, 2, 4 taps instead of the nine a zero-stuffed stride-1 conv would run.  Tap k of the class =
 // (ky', kx') = (1 + dy, 1 + dx), ky' outer; layout [cout'/64][k][cin'/16][s 4][lane 64] with cin' = cout, cout' = cin.
-__global__ __launch_bounds__(256) void disc_pack_par_kernel(const float* __restrict__ w, float* __restrict__ out, int cin, int cout,
+template <typename OutT>
+__global__ __launch_bounds__(256) void disc_pack_par_kernel(const float* __restrict__ w, OutT* __restrict__ out, int cin, int cout,
                                                             int py, int px, size_t total)
 {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -66,7 +72,7 @@ __global__ __launch_bounds__(256) void disc_pack_par_kernel(const float* __restr
     const int cip = 16 * ch + 4 * kq + j;                                // packed input channel = the layer's co
     const int dy = k / (px + 1), dx = k % (px + 1);
     const int ky = py + 1 - 2 * dy, kx = px + 1 - 2 * dx;
-    out[idx] = w[((size_t)cip * cin + cop) * 9 + ky * 3 + kx];
+    put1(out + idx, w[((size_t)cip * cin + cop) * 9 + ky * 3 + kx]);
 }
 
 // stem pack [j 7][s 4][lane 64] (pack_disc_stem) and tail pack [tap 9][cin] (pack_disc_tail)
@@ -468,9 +474,10 @@ __global__ __launch_bounds__(256) void clip_scale_kernel(float* __restrict__ g, 
 
 }  // namespace
 
-hipError_t launch_disc_pack(const float* w, float* out, int cin, int cout, int mode, hipStream_t s)
+hipError_t launch_disc_pack(const float* w, float* out, int cin, int cout, int mode, hipStream_t s, bool bf16)
 {
     if (mode == 2 || mode == 3) {                                        // 2: stem pack, 3: tail pack
+        if (bf16) return hipErrorInvalidValue;                           // (those two layers keep fp32 products)
         const int total = mode == 3 ? 9 * cin : 7 * 4 * 64;
         hipLaunchKernelGGL(disc_pack_small_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, out, cin, mode == 3);
         return hipGetLastError();
@@ -481,14 +488,23 @@ hipError_t launch_disc_pack(const float* w, float* out, int cin, int cout, int m
         for (int c = 0; c < 4; ++c) {
             const int py = c >> 1, px = c & 1;
             const size_t total = (size_t)(py + 1) * (px + 1) * cin * cout;
-            hipLaunchKernelGGL(disc_pack_par_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, out + off, cin, cout,
-                               py, px, total);
+            if (bf16)
+                hipLaunchKernelGGL(disc_pack_par_kernel<bf16_t>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w,
+                                   (bf16_t*)out + off, cin, cout, py, px, total);
+            else
+                hipLaunchKernelGGL(disc_pack_par_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, out + off,
+                                   cin, cout, py, px, total);
             off += total;
         }
         return hipGetLastError();
     }
     const size_t total = (size_t)cin * cout * 9;
-    hipLaunchKernelGGL(disc_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, out, cin, cout, mode, total);
+    if (bf16)
+        hipLaunchKernelGGL(disc_pack_kernel<bf16_t>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, (bf16_t*)out, cin, cout,
+                           mode, total);
+    else
+        hipLaunchKernelGGL(disc_pack_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, out, cin, cout, mode,
+                           total);
     return hipGetLastError();
 }
 

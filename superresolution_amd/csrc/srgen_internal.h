@@ -263,6 +263,8 @@ struct DiscConvArgs {          // conv Cin -> Cout (Cin % 16 == 0, Cout % 64 == 
     // stride-2 data gradient, one output parity class (disc_conv_kernel<.., PAR = true>)
     unsigned long long taps = 0;   // 4-bit tap ids (ky*3 + kx), real taps first, 15 = padding
     int ntaps = 0, nreal = 0, py = 0, px = 0, FH = 0, FW = 0;
+    int bf16 = 0;                  // 1: wpack holds bf16 units of four (launch_disc_pack with bf16 = true) and the products are
+                                   // bf16 x bf16 with fp32 accumulation; tensors stay fp32
 };
 constexpr int kDiscZeroFloats = 512;
 struct DiscTailArgs {          // conv Cin -> 1, stride 1, pad 1, no activation
@@ -281,7 +283,7 @@ hipError_t launch_ragan_loss(const float* real, const float* fake, size_t n_real
 
 // ---- GAN-phase backward operators (srdisc_train_kernels.hip) ---------------------------------------------------------
 // packs from live OIHW weights on the device: mode 0 forward conv, 1 data-gradient conv, 2 stem, 3 tail
-hipError_t launch_disc_pack(const float* w, float* out, int cin, int cout, int mode, hipStream_t s);
+hipError_t launch_disc_pack(const float* w, float* out, int cin, int cout, int mode, hipStream_t s, bool bf16 = false);
 size_t disc_wgrad_scratch_bytes(int n, int oh, int cin, int cout);
 hipError_t launch_disc_wgrad(const float* in, const float* dpre, int n, int h, int w, int cin, int cout, int stride, float* dw,
                              float* dbias, void* scratch, hipStream_t s);

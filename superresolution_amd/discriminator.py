@@ -74,6 +74,9 @@ class Discriminator(nn.Module):
         self._weights_sig: Dict[int, Tuple] = {}
         self._workspace: Dict[int, torch.Tensor] = {}
         self._dgrads: Dict[int, object] = {}            # device index -> gan_training.DiscriminatorGrad
+        # products of the 64..512-channel convs under autograd: "auto" = bf16 products inside torch.autocast(bfloat16) (or
+        # with a bf16 input), the way train.py:150,168 call the discriminator, fp32 otherwise; or "fp32" / "bf16"
+        self.train_products = "auto"
 
     def _init_weights(self) -> None:                                      # Discriminator.py:42-47
         for m in self.modules():
@@ -138,7 +141,8 @@ class Discriminator(nn.Module):
         if p.device != x.device:
             raise RuntimeError(f"Input type ({x.device}) and weight type ({p.device}) should be the same")
         # the reference runs D under torch.autocast(bfloat16) (train.py:150,166): bf16 inputs / bf16 autocast are
-        # accepted, the arithmetic stays fp32 (the stricter one) and only the returned logits are rounded
+        # accepted; tensors stay fp32 and the returned logits are rounded.  Forward values (no graph) are computed with
+        # fp32 products; under autograd ``train_products`` decides (bf16 products in this case by default)
         bf16_out = x.dtype == torch.bfloat16 or (
             torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16)
         if x.dtype not in (torch.float32, torch.bfloat16):
@@ -195,6 +199,9 @@ class Discriminator(nn.Module):
             dg = self._dgrads[idx] = DiscriminatorGrad(self, Workspace(x.device))
         names = [k for k, _ in self.named_parameters()]
         params = [p for _, p in self.named_parameters()]
+        if self.train_products not in ("auto", "fp32", "bf16"):
+            raise RuntimeError(f"train_products '{self.train_products}': expected auto, fp32 or bf16")
+        dg.products = ("bf16" if bf16_out else "fp32") if self.train_products == "auto" else self.train_products
         with torch.cuda.device(idx):
             y = A.DiscriminatorFn.apply(dg, names, x if x.dtype == torch.float32 else x.float(), *params)
         return y.to(torch.bfloat16) if bf16_out else y

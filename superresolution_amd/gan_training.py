@@ -84,14 +84,21 @@ class DiscriminatorGrad:
             raise RuntimeError("DiscriminatorGrad needs the discriminator's fp32 parameters on a ROCm device; there is no CPU fallback")
         self.dev = p0.device
         self.strides = [1, 2, 1, 2, 1, 2, 1, 2, 1, 1]
+        # products of the eight 64..512-channel convs (forward and data gradient): "fp32" (exact-fp32 MFMA) or "bf16" (what
+        # torch.autocast(bfloat16) gives them at train.py:150,168: operands rounded to bf16 where they are multiplied, fp32
+        # accumulation; tensors stay fp32, the stem, the tail and every weight gradient keep fp32 products).  A forward
+        # remembers its setting for its backward
+        self.products = "fp32"
 
-    def _pack(self, conv: torch.nn.Conv2d, mode: int) -> torch.Tensor:
+    def _pack(self, conv: torch.nn.Conv2d, mode: int, bf16: bool = False) -> torch.Tensor:
         w = conv.weight.detach().contiguous()
         cout, cin = w.shape[0], w.shape[1]
         numel = {0: w.numel(), 1: w.numel(), 2: 7 * 4 * 64, 3: 9 * cin, 4: w.numel()}[mode]
-        out = torch.empty(numel, dtype=torch.float32, device=w.device)
+        bf16 = bf16 and mode in (0, 1, 4)
+        out = torch.empty(numel, dtype=torch.bfloat16 if bf16 else torch.float32, device=w.device)
+        fn = _lib.lib().srdisc_pack_bf16 if bf16 else _lib.lib().srdisc_pack
         with torch.cuda.device(w.device):
-            _lib.check(_lib.lib().srdisc_pack(w.data_ptr(), cin, cout, mode, out.data_ptr(), _stream(w)))
+            _lib.check(fn(w.data_ptr(), cin, cout, mode, out.data_ptr(), _stream(w)))
         return out
 
     # -- forward --------------------------------------------------------------------------------------------------------
@@ -100,6 +107,10 @@ class DiscriminatorGrad:
         if not x.is_cuda or x.dim() != 4 or x.shape[1] != 3:
             raise RuntimeError(f"expected an (n, 3, h, w) ROCm tensor, got {tuple(x.shape)} on {x.device}; there is no CPU fallback")
         L = _lib.lib()
+        if self.products not in ("fp32", "bf16"):
+            raise RuntimeError(f"discriminator products '{self.products}': expected fp32 or bf16")
+        b16 = self.products == "bf16"
+        conv_fn = L.srdisc_conv_nhwc_bf16p if b16 else L.srdisc_conv_nhwc
         xc = x.detach().to(torch.float32).contiguous()
         n, _, h, w = xc.shape
         acts: List[torch.Tensor] = []
@@ -118,8 +129,8 @@ class DiscriminatorGrad:
                 cout, cin = conv.weight.shape[0], conv.weight.shape[1]
                 oh, ow = (_down(ch), _down(cw)) if st == 2 else (ch, cw)
                 o = torch.empty((n, oh, ow, cout), dtype=torch.float32, device=self.dev)
-                _lib.check(L.srdisc_conv_nhwc(acts[-1].data_ptr(), self._pack(conv, 0).data_ptr(), conv.bias.detach().data_ptr(),
-                                              None, o.data_ptr(), n, ch, cw, cin, cout, st, SLOPE, s))
+                _lib.check(conv_fn(acts[-1].data_ptr(), self._pack(conv, 0, b16).data_ptr(), conv.bias.detach().data_ptr(),
+                                   None, o.data_ptr(), n, ch, cw, cin, cout, st, SLOPE, s))
                 acts.append(o)
                 ch, cw = oh, ow
                 sizes.append((ch, cw))
@@ -127,7 +138,7 @@ class DiscriminatorGrad:
             logits = torch.empty((n, 1, ch, cw), dtype=torch.float32, device=self.dev)
             _lib.check(L.srdisc_tail(acts[-1].data_ptr(), self._pack(c9, 3).data_ptr(), c9.bias.detach().data_ptr(),
                                      logits.data_ptr(), n, ch, cw, c9.weight.shape[1], s))
-        return logits, {"x": xc, "acts": acts, "sizes": sizes}
+        return logits, {"x": xc, "acts": acts, "sizes": sizes, "bf16": b16}
 
     # -- backward -------------------------------------------------------------------------------------------------------
     def _grad_views(self, conv) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -142,7 +153,9 @@ class DiscriminatorGrad:
         """``into``: {state_dict key -> contiguous fp32 tensor} the weight / bias gradients are WRITTEN to (the autograd
         wrapper hands them to torch, which accumulates); default: ADDED to ``p.grad``, as ``loss.backward()`` would."""
         L, ws = _lib.lib(), self.ws
-        acts, sizes, xc = saved["acts"], saved["sizes"], saved["x"]
+        acts, sizes, xc, b16 = saved["acts"], saved["sizes"], saved["x"], saved.get("bf16", False)
+        conv_fn = L.srdisc_conv_nhwc_bf16p if b16 else L.srdisc_conv_nhwc
+        dgrad2_fn = L.srdisc_conv_dgrad2_bf16p if b16 else L.srdisc_conv_dgrad2
         n = xc.shape[0]
         dl = dlogits.detach().to(torch.float32).contiguous()
         need = ctypes.c_size_t()
@@ -186,11 +199,11 @@ class DiscriminatorGrad:
                     break
                 nxt = torch.empty((n, ih, iw, cin), dtype=torch.float32, device=self.dev)
                 if st == 2:                        # one launch per output parity: only the taps that reach it
-                    _lib.check(L.srdisc_conv_dgrad2(dpre.data_ptr(), self._pack(conv, 4).data_ptr(), acts[i - 1].data_ptr(),
-                                                    nxt.data_ptr(), n, ih, iw, cin, cout, SLOPE, s))
+                    _lib.check(dgrad2_fn(dpre.data_ptr(), self._pack(conv, 4, b16).data_ptr(), acts[i - 1].data_ptr(),
+                                         nxt.data_ptr(), n, ih, iw, cin, cout, SLOPE, s))
                 else:
-                    _lib.check(L.srdisc_conv_nhwc(dpre.data_ptr(), self._pack(conv, 1).data_ptr(), None, acts[i - 1].data_ptr(),
-                                                  nxt.data_ptr(), n, ih, iw, cout, cin, 1, SLOPE, s))
+                    _lib.check(conv_fn(dpre.data_ptr(), self._pack(conv, 1, b16).data_ptr(), None, acts[i - 1].data_ptr(),
+                                       nxt.data_ptr(), n, ih, iw, cout, cin, 1, SLOPE, s))
                 dpre = nxt
             c0 = self.convs[0]
             h0, w0 = sizes[0]
@@ -218,9 +231,9 @@ class GanStep:
     def __init__(self, generator, discriminator, lr_g: float = 1e-4, lr_d: float = 1e-6, weight_adversarial: float = 0.005,
                  weight_pixel: float = 1.0, weight_ssim: float = 0.3, grad_clip_norm: float = 10.0, real_label: float = 0.9,
                  fake_label: float = 0.1, group=None, precision: str = "auto", reuse_forward: bool = False):
-        # precision: the generator's 3x3 conv products, as PretrainStep ("auto": f16 products when called inside
-        # torch.autocast with a 16-bit dtype, the way train.py:148-149,166-167 call the generator); the discriminator's
-        # convs stay on the exact-fp32 MFMA
+        # precision: the arithmetic of the generator's step, as PretrainStep ("auto": that of the autocast dtype, the way
+        # train.py:148-149,166-167 call the generator); with "bf16" the discriminator's 64..512-channel convs take bf16
+        # products too (DiscriminatorGrad.products), otherwise they stay on the exact-fp32 MFMA
         self.gen = PretrainStep(generator, lr=lr_g, ssim_weight=weight_ssim, l1_weight=weight_pixel, group=group,
                                 precision=precision)
         # reuse_forward: in an iteration that updates the discriminator the reference runs the generator twice on the same
@@ -250,10 +263,15 @@ class GanStep:
         return out                                                   # {discriminator_loss, generator_loss}
 
     # train.py:145-159
+    def _set_products(self) -> str:
+        prec = resolve_precision(self.gen.precision)
+        self.dgrad.products = "bf16" if prec == "bf16" else "fp32"
+        return prec
+
     def d_step(self, lr_img: torch.Tensor, hr_img: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         """Updates the discriminator; returns (d_loss, real_logits) -- the logits the generator step of the same iteration
         uses (computed BEFORE the update, as in the reference)."""
-        with conv_precision(resolve_precision(self.gen.precision)), packed_weights(self.gen.pack_jobs(backward=False)):
+        with conv_precision(self._set_products()), packed_weights(self.gen.pack_jobs(backward=False)):
             return self._d_step(lr_img, hr_img)
 
     def _d_step(self, lr_img: torch.Tensor, hr_img: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -281,12 +299,13 @@ class GanStep:
         return d_loss, real_logits
 
     def real_logits(self, hr_img: torch.Tensor) -> torch.Tensor:     # train.py:161-163
+        self._set_products()
         logits, _ = self.dgrad.forward(hr_img)
         return logits
 
     # train.py:165-176
     def g_step(self, lr_img: torch.Tensor, hr_img: torch.Tensor, real_logits: torch.Tensor) -> Dict[str, torch.Tensor]:
-        with conv_precision(resolve_precision(self.gen.precision)), packed_weights(self.gen.pack_jobs()):
+        with conv_precision(self._set_products()), packed_weights(self.gen.pack_jobs()):
             return self._g_step(lr_img, hr_img, real_logits)
 
     def _g_step(self, lr_img: torch.Tensor, hr_img: torch.Tensor, real_logits: torch.Tensor) -> Dict[str, torch.Tensor]:

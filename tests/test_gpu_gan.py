@@ -66,6 +66,101 @@ def test_discriminator_backward_vs_torch_autograd(shape):
     assert max_rel(disc_convs(d)[3].weight.grad.cpu().numpy(), (2 * w0).cpu().numpy()) <= 1e-6
 
 
+def _rb(t):
+    return t.to(torch.bfloat16).float()
+
+
+@pytest.mark.parametrize("shape", [(2, 37, 53), (1, 125, 125)])
+def test_discriminator_bf16_products_vs_torch_emulation(shape):
+    """DiscriminatorGrad.products = "bf16" (what autocast gives the 64..512-channel convs at train.py:150,168): tensors
+    stay fp32, a conv's activation (forward) or gradient (data gradient) operand and its weights are rounded to bf16 where
+    they are multiplied, accumulation is fp32; the stem, the tail and every weight gradient keep fp32 products.
+    (a) every layer's forward and data gradient against exactly that arithmetic written with stock torch ops on the CPU, fed
+        the SAME operands (products of bf16 numbers are exact in fp32: what is left is summation order; bar 2e-5 of max --
+        chained through the network instead, two correct implementations drift apart to the bf16 rounding noise itself,
+        because a 1e-6 difference decides which way an operand rounds);
+    (b) the whole forward / backward against the plain fp32 torch reference: a bf16-sized deviation, and not zero."""
+    from superresolution_amd import Discriminator, training as T
+    from superresolution_amd.gan_training import DiscriminatorGrad, disc_convs
+    torch.manual_seed(11)
+    d = Discriminator().cuda()
+    with torch.no_grad():
+        for c in disc_convs(d):
+            c.bias.uniform_(-0.05, 0.05)
+    n, h, w = shape
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand((n, 3, h, w), generator=g)
+    strides = [1, 2, 1, 2, 1, 2, 1, 2, 1, 1]
+    ws = [(c.weight.detach().cpu(), c.bias.detach().cpu()) for c in disc_convs(d)]
+    nchw = lambda t: t.permute(0, 3, 1, 2).contiguous().cpu()
+    lr_d = lambda a: torch.where(a > 0, torch.ones_like(a), torch.full_like(a, 0.2))
+    dg = DiscriminatorGrad(d, T.Workspace(torch.device("cuda", 0)))
+    dg.products = "bf16"
+    logits, saved = dg.forward(x.cuda())
+    assert saved["bf16"]
+    acts = [nchw(a) for a in saved["acts"]]
+    # (a) forward, layer by layer on the GPU's own inputs
+    for i in range(1, 9):
+        ref = F.leaky_relu(F.conv2d(_rb(acts[i - 1]), _rb(ws[i][0]), ws[i][1], stride=strides[i], padding=1), 0.2)
+        e = max_rel(acts[i].numpy(), ref.numpy())
+        print(f"  layer {i} forward (bf16 products) vs emulation on the same input: {e:.2e}")
+        assert e <= 2e-5, (i, e)
+    # (a) data gradient of every layer: the operator on a random gradient and the saved activation below
+    import ctypes
+    from superresolution_amd import _lib
+    L = _lib.lib()
+    s = torch.cuda.current_stream().cuda_stream
+    for i in range(1, 9):
+        conv, st = disc_convs(d)[i], strides[i]
+        cout, cin = conv.weight.shape[0], conv.weight.shape[1]
+        below, here = acts[i - 1], acts[i]
+        dpre = torch.randn(here.shape, generator=g) * 1e-3
+        op = (below.shape[2] - ((dpre.shape[2] - 1) * st + 1), below.shape[3] - ((dpre.shape[3] - 1) * st + 1))
+        ref = F.conv_transpose2d(_rb(dpre), _rb(ws[i][0]), stride=st, padding=1, output_padding=op) * lr_d(below)
+        dp = dpre.permute(0, 2, 3, 1).contiguous().cuda()
+        out = torch.empty_like(saved["acts"][i - 1])
+        ih, iw = below.shape[2], below.shape[3]
+        if st == 2:
+            _lib.check(L.srdisc_conv_dgrad2_bf16p(dp.data_ptr(), dg._pack(conv, 4, True).data_ptr(), saved["acts"][i - 1].data_ptr(),
+                                                  out.data_ptr(), n, ih, iw, cin, cout, 0.2, s))
+        else:
+            _lib.check(L.srdisc_conv_nhwc_bf16p(dp.data_ptr(), dg._pack(conv, 1, True).data_ptr(), None, saved["acts"][i - 1].data_ptr(),
+                                                out.data_ptr(), n, ih, iw, cout, cin, 1, 0.2, s))
+        e = max_rel(nchw(out).numpy(), ref.numpy())
+        print(f"  layer {i} data gradient (stride {st}, bf16 products) vs emulation: {e:.2e}")
+        assert e <= 2e-5, (i, e)
+    # (b) the whole thing against plain fp32 autograd
+    xr = x.clone().requires_grad_()
+    ref_logits, ps = _torch_disc(d, xr)
+    dl = torch.randn(ref_logits.shape, generator=g) / ref_logits.numel()
+    ref_logits.backward(dl)
+    dev = max_rel(logits.cpu().numpy(), ref_logits.detach().numpy())
+    print("bf16-product logits vs the fp32 reference", dev)
+    assert 1e-5 <= dev <= 3e-2
+    dimg = dg.backward(dl.cuda(), saved, want_wgrad=True, want_dimg=True)
+
+    def rel_cos(a, b_):
+        a, b_ = a.double().flatten(), b_.double().flatten()
+        return float((a - b_).norm() / b_.norm()), float(a @ b_ / (a.norm() * b_.norm()))
+    # A freshly initialised 10-layer LeakyReLU chain fed noise: the gradient of a noise functional of its logits is the
+    # most rounding-sensitive quantity there is -- every sign flip of a pre-activation near zero switches a path.  The
+    # yardstick is therefore what torch's OWN bf16 autocast does to the same gradients (stock ops, CPU): this path has to
+    # stay within 2x of that deviation per tensor (measured: 0.9x - 1.7x, the same size: 6 - 14 % for both).
+    xa = x.clone().requires_grad_()
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        ac_logits, pa = _torch_disc(d, xa)
+    ac_logits.float().backward(dl)
+    r, c = rel_cos(dimg.cpu(), xr.grad)
+    ra, ca = rel_cos(xa.grad, xr.grad)
+    print(f"  image gradient vs fp32: rel {r:.2e}, cosine {c:.6f}   (torch autocast: rel {ra:.2e}, cosine {ca:.6f})")
+    assert 1e-5 <= r <= 2.0 * ra
+    for i, (cv, (w_, b_), (wa, _)) in enumerate(zip(disc_convs(d), ps, pa)):
+        r, c = rel_cos(cv.weight.grad.cpu(), w_.grad)
+        ra, ca = rel_cos(wa.grad, w_.grad)
+        print(f"  layer {i} weight gradient vs fp32: rel {r:.2e}, cosine {c:.6f}   (torch autocast: rel {ra:.2e}, cosine {ca:.6f})")
+        assert r <= 2.0 * ra, (i, r, ra)
+
+
 def test_ragan_loss_grad_vs_torch_autograd():
     from superresolution_amd.gan_training import ragan_loss_grad
     g = torch.Generator().manual_seed(2)
