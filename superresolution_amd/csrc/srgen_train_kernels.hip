@@ -810,10 +810,21 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const T* __restrict__
     if (tid < BNB_THREADS) {
         const int cg = tid % CPP, row = tid / CPP;
         float rstd[V], mr[V], pp[V], qq[V], sl[V];
+        {                                                        // bn_consts for this thread's channels, from 16-byte loads
+            float mean[V], var[V], ga[V], be[V];
+            ldf<V>(stats + cg * V, mean);
+            ldf<V>(stats + 96 + cg * V, var);
+            ldf<V>(gamma + cg * V, ga);
+            ldf<V>(beta + cg * V, be);
+            if (slope) ldf<V>(slope + cg * V, sl);
 #pragma unroll
-        for (int e = 0; e < V; ++e) {
-            bn_consts(stats, gamma, beta, cg * V + e, rstd[e], mr[e], pp[e], qq[e]);
-            sl[e] = slope ? slope[cg * V + e] : 1.f;
+            for (int e = 0; e < V; ++e) {
+                rstd[e] = 1.0f / sqrtf(var[e] + 1e-5f);
+                mr[e] = mean[e] * rstd[e];
+                pp[e] = ga[e] * rstd[e];
+                qq[e] = be[e] - mean[e] * pp[e];
+                if (!slope) sl[e] = 1.f;
+            }
         }
         const size_t per = (npix + gridDim.x - 1) / gridDim.x;
         const size_t p0 = (size_t)blockIdx.x * per, p1 = p0 + per < npix ? p0 + per : npix;
