@@ -16,7 +16,7 @@ import pytest
 import torch
 
 from conftest import GOLDEN
-from test_gpu_training import _hash_tensor, _nhwc, _resblock, _sample_rel, _step_batch
+from test_gpu_training import _hash_tensor, _nhwc, _ref_weighted_l1, _resblock, _sample_rel, _step_batch
 
 pytestmark = pytest.mark.gpu
 ROUND = 2.0 ** -7       # of the tensor's max: one bf16 rounding of the stored result
@@ -207,6 +207,47 @@ def test_pretrain_step_bf16_vs_reference_fp32_and_autocast_golden():
     assert float(np.median(ratios)) <= 1.0
     for p in g.parameters():
         assert p.grad.dtype == torch.float32 and bool(torch.isfinite(p.grad).all())
+
+
+def test_reference_loop_body_under_bf16_autocast_vs_reference_autocast_golden():
+    """train.py:90-95 EXACTLY as the reference has it -- inside ``torch.autocast(device_type='cuda', dtype=torch.bfloat16)``
+    -- on the drop-in Generator with a stock AdamW: the forward runs the 16-bit step's operators, ``sr`` comes back bf16,
+    torch differentiates the reference's own loss expressions, ``loss.backward()`` reaches the HIP backward through
+    autograd.GeneratorTrainFn.  Against ONE step of the real reference run the same way (train_step_autocast.npz) and in
+    fp32 (train_step.npz): every sampled gradient deviates from the reference's fp32 gradient by no more than 1.5x what
+    the reference's own autocast gradient does."""
+    from oracle import torch_ref as TR
+    from superresolution_amd import Generator, weights as W
+    g32 = np.load(os.path.join(GOLDEN, "train_step.npz"))
+    gac = np.load(os.path.join(GOLDEN, "train_step_autocast.npz"))
+    generator = Generator()
+    generator.load_state_dict(W.synthetic_state_dict(0))
+    generator = generator.cuda()
+    optimizer = torch.optim.AdamW(generator.parameters(), lr=1e-4)
+    generator.train()
+    lr, hr = _step_batch()
+    optimizer.zero_grad()
+    with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+        sr = generator(lr)
+        loss = _ref_weighted_l1(sr, hr) + 0.1 * (1 - TR.ssim(sr, hr))
+    loss.backward()
+    optimizer.step()
+    assert sr.dtype == torch.bfloat16 and sr.grad_fn is not None
+    ref_loss, ac_loss = float(g32["loss"]), float(gac["loss"])
+    print("loss: fp32 reference", ref_loss, "reference autocast", ac_loss, "the loop body on the drop-in", loss.item())
+    assert abs(loss.item() - ref_loss) <= 2.0 * abs(ac_loss - ref_loss) + 1e-4 * abs(ref_loss)
+    P = dict(generator.named_parameters())
+    ratios = []
+    for k in g32.files:
+        if not k.startswith("grad_sample_"):
+            continue
+        v = P[k[len("grad_sample_"):]].grad.detach().float().flatten()[::7].cpu().numpy()
+        ours, theirs = _sample_rel(v, g32[k]), _sample_rel(gac[k], g32[k])
+        print(f"  {k}: drop-in {ours:.2e}, reference autocast {theirs:.2e}")
+        assert ours <= (1.5 if v.size > 4 else 3.0) * theirs + 2e-3, (k, ours, theirs)
+        ratios.append(ours / theirs)
+    print("  deviation / the reference autocast's: median", float(np.median(ratios)), "max", max(ratios))
+    assert float(np.median(ratios)) <= 1.1
 
 
 def test_pretrain_steps_bf16_reduce_the_loss_like_the_fp32_step():
