@@ -499,6 +499,13 @@ int srgen_create(const srgen_config* cfg, srgen_handle** out)
         }
         h->f32_split = e[0] == 0 || strcmp(e, "split") == 0;
         h->f32_wino = strcmp(e, "wino") == 0;
+#ifndef SRGEN_WITH_DIRECT
+        if (!h->f32_split && !h->f32_wino) {
+            delete h;
+            return fail(SRGEN_E_INVALID, "SRGEN_F32_CONV3X3=direct: this libsrgen.so was built without the direct fp32 kernel "
+                                         "(a development cross-check: make -C superresolution_amd/csrc DIRECT=1)");
+        }
+#endif
     }
     if (const char* e = getenv("SRGEN_SPLIT_NO_AMAX")) h->split_amax = !(e[0] && strcmp(e, "0") != 0);
     *out = h;
@@ -746,7 +753,12 @@ static int run_forward(srgen_handle* h, const void* x, void* y, void* workspace,
         hipError_t e = tick(shuffle ? SRGEN_K_CONV3X3_UP : (H == kLR ? SRGEN_K_CONV3X3_TRUNK : SRGEN_K_CONV3X3_HR));
         if (e != hipSuccess) return e;
         e = bf ? launch_conv3x3_bf16(a, s) : split ? launch_conv3x3_f32_split(a, s)
-               : wino ? launch_conv3x3_f32_wino(a, s) : launch_conv3x3_f32(a, s);
+               : wino ? launch_conv3x3_f32_wino(a, s)
+#ifdef SRGEN_WITH_DIRECT
+                      : launch_conv3x3_f32(a, s);
+#else
+                      : hipErrorInvalidValue;         // (srgen_create refuses the direct path in this build)
+#endif
         if (e != hipSuccess) return e;
         return tock();
     };

@@ -156,6 +156,21 @@ def test_split_path_one_hot_pixel_image(homogeneous):
     assert max(errs) <= FP32_TOL
 
 
+def _require_direct_build(monkeypatch):
+    """SRGEN_F32_CONV3X3=direct needs a library built with ``make DIRECT=1`` (the default build leaves that development
+    kernel out and says so at handle creation): skip where it is absent."""
+    from superresolution_amd import Generator, weights as W
+    monkeypatch.setenv("SRGEN_F32_CONV3X3", "direct")
+    g = Generator()
+    g.load_state_dict(W.synthetic_state_dict(0))
+    try:
+        g.cuda().eval()(torch.zeros(1, 3, 64, 64, device="cuda"))
+    except RuntimeError as e:
+        if "built without the direct fp32 kernel" in str(e):
+            pytest.skip("libsrgen.so built without DIRECT=1")
+        raise
+
+
 @pytest.mark.parametrize("path", ["direct", "wino"])
 def test_fp32_exact_mfma_conv_kernels_match_golden_and_the_default(gen, golden, golden_inputs, monkeypatch, path):
     """The fp32 3x3 convs run the split-f16 kernel by default (fp32 tensors and accumulation, every product formed
@@ -163,6 +178,8 @@ def test_fp32_exact_mfma_conv_kernels_match_golden_and_the_default(gen, golden, 
     (SRGEN_F32_CONV3X3=direct | wino at handle creation) must meet the same bar, and each must agree with the
     default far inside it, on a batch whose work items straddle rows, images and workgroup counts."""
     from superresolution_amd import Generator, weights as W
+    if path == "direct":
+        _require_direct_build(monkeypatch)
     monkeypatch.setenv("SRGEN_F32_CONV3X3", path)
     g = Generator()
     g.load_state_dict(W.synthetic_state_dict(0))
@@ -393,6 +410,8 @@ def test_pixel_shuffle_store_is_bit_exact_on_hip(dtype, path, monkeypatch):
     if path is not None:
         if dtype == torch.bfloat16:
             pytest.skip("one bf16 3x3 kernel")
+        if path == "direct":
+            _require_direct_build(monkeypatch)
         monkeypatch.setenv("SRGEN_F32_CONV3X3", path)
     g = Generator()
     g.load_state_dict(_shuffle_kat_state_dict())
