@@ -8,13 +8,19 @@
 //     out[y][x][co]     = bias[co] + sum_kx T[y][x+kx-4][kx*3+co]                         (9-term shifted sum through LDS)
 // x' runs over the 128 image columns only (T outside the image is identically zero).
 //
-// Workgroup = 8 waves = 4 output rows x 128 columns; wave (row r, half mh) owns T of row y0 + r, columns 64 mh .. 64 mh + 63
-// as two 32 x 32 accumulator tiles.  K runs as 6 chunks of 16 ci x 9 ky.  Per chunk the 12 x 128 halo pixels are staged
-// in LDS as {16 hi, 16 lo} f16 records (pitch 80 B as in the 3x3 kernel: 120 KB, one workgroup per CU, two waves per
-// SIMD).  The next chunk's pixels are fetched into registers at the start of a chunk's MFMAs and split into (hi, lo)
-// under its last ones, so only the LDS writes sit between the chunk's two barriers.  The weight fragments of a chunk
-// (9 ky x {hi, lo}, 16 B per lane each) live in registers and are re-loaded for the next chunk one ky at a time as they
-// fall free.
+// Workgroup = 8 waves = 4 output rows x 128 columns.  K runs as 6 chunks of 16 ci x 9 ky.  Per chunk the 12 x 128 halo
+// pixels are staged in LDS as {16 hi, 16 lo} f16 records (pitch 80 B as in the 3x3 kernel: 120 KB, one workgroup per CU,
+// two waves per SIMD).  Halo row i feeds output row r through kernel row ky = i - r: a wave is INPUT-row stationary --
+// wave (column tile ct of 32, half ih) reads the fragments of halo rows 6 ih .. 6 ih + 5 of its columns ONCE per chunk and
+// multiplies each into every output row it reaches (1 .. 4 of them), so a chunk costs a wave 12 fragment reads for its
+// 54 MFMAs (the output-row-stationary first version read 36: with N = 32 a pixel fragment is used by three MFMAs only and
+// the LDS pipe was as busy as the matrix pipe -- 1.35 ms per batch-256 launch).  The two halves cover 18 (row, ky) pairs
+// each (ih = 0: ky 0 .. 5, ih = 1: ky 3 .. 8 -- six kernel rows of weight fragments in registers instead of nine; half 1 is
+// half 0 mirrored, so both run one instruction stream) and hold four accumulator tiles (one per output row); their sums
+// meet in the T buffer.  The next chunk's pixels are
+// fetched into registers at the start of a chunk's MFMAs and split into (hi, lo) under its last ones, so only the LDS
+// writes sit between the chunk's two barriers.  A kernel row's weight fragments are re-loaded for the next chunk as
+// soon as its last product of the chunk is issued.
 #include "srgen_internal.h"
 
 namespace srgen {
@@ -56,24 +62,28 @@ __global__ __launch_bounds__(NTHR, 1) void head_f32s_kernel(HeadArgs a)
     const int kx = a.in_amax ? __builtin_amdgcn_readfirstlane(split_exp(a.in_amax[n])) : 0;
     const float in_mul = pow2f(kx), out_mul = pow2f(-(kw + kx));
 
-    f32x16 acc[2];
+    const int ct = w & 3, ih = w >> 2;                // main loop: column tile, half of the halo rows
+    f32x16 acc[4];                                    // one 32 x 32 tile of T per output row
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+        for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
 
     // staging: 12 x 128 pixels x 16 ci (fp32) = 6,144 16-byte pieces per chunk, 12 per thread: piece `it` of a thread is
     // halo row `it`, column tid / 4, channels 4 (tid % 4) .. + 3 of the chunk -- one per-thread offset, the row offsets
     // and the row validity (rows above / below the image are the conv's zero padding) are wave-uniform
     f32x4 stage[PIECES];
     h4 chi[PIECES], clo[PIECES];
-    const int voff = (tid >> 2) * kC + (tid & 3) * 4;
+    const unsigned voffb = (unsigned)(((tid >> 2) * kC + (tid & 3) * 4) * 4);     // bytes; the row pointer is wave-uniform (scalar)
     auto row_ok = [&](int it) { return (unsigned)(y0 - 4 + it) < (unsigned)kHR; };
     auto load_stage = [&](int g) {
+        unsigned vo = voffb + (unsigned)g * 64u;      // ONE per-thread offset; the twelve row pointers stay scalar
+        asm volatile("" : "+v"(vo));                  // (opaque: else the twelve sums are hoisted as 64-bit vector addresses)
 #pragma unroll
         for (int it = 0; it < PIECES; ++it) {
             const int cy = min(max(y0 - 4 + it, 0), kHR - 1);
-            stage[it] = *(const f32x4*)(in + (size_t)cy * kHR * kC + g * 16 + voff);
+            const char* rowp = (const char*)(in + (size_t)cy * kHR * kC);
+            stage[it] = *(const f32x4*)(rowp + vo);
         }
     };
     auto convert = [&](int it) {
@@ -85,12 +95,14 @@ __global__ __launch_bounds__(NTHR, 1) void head_f32s_kernel(HeadArgs a)
             clo[it][e] = (_Float16)(v - (float)chi[it][e]);
         }
     };
-    char* const rec0 = lds + (tid >> 2) * PSB + (tid & 3) * 8;
+    const unsigned rec0 = (unsigned)((tid >> 2) * PSB + (tid & 3) * 8);
     auto store_stage = [&]() {
+        unsigned r0 = rec0;                           // (opaque: one address register and twelve adds per chunk instead of
+        asm volatile("" : "+v"(r0));                  // twelve hoisted address registers -- the row pitch exceeds a DS offset)
 #pragma unroll
         for (int it = 0; it < PIECES; ++it) {
-            *(h4*)(rec0 + it * COLS * PSB) = chi[it];
-            *(h4*)(rec0 + it * COLS * PSB + 32) = clo[it];
+            *(h4*)(lds + r0 + it * COLS * PSB) = chi[it];
+            *(h4*)(lds + r0 + it * COLS * PSB + 32) = clo[it];
         }
     };
     auto barrier = [&]() {
@@ -99,56 +111,64 @@ __global__ __launch_bounds__(NTHR, 1) void head_f32s_kernel(HeadArgs a)
         asm volatile("" ::: "memory");
     };
 
-    h8 bh[9], bl[9];
-#pragma unroll
-    for (int ky = 0; ky < 9; ++ky) {
-        bh[ky] = wp[(ky * 2 + 0) * 64 + lane];
-        bl[ky] = wp[(ky * 2 + 1) * 64 + lane];
-    }
     load_stage(0);
 #pragma unroll
     for (int it = 0; it < PIECES; ++it) convert(it);
     store_stage();
-    barrier();
 
-    // this lane's pixel fragments: row (row + ky), column 64 mh + 32 mt + p, K half h
-    const char* const Ax = lds + (row * COLS + 64 * mh + p) * PSB + 16 * h;
-
+    // Half 1 is half 0 mirrored -- halo rows 11 - ii instead of ii, output rows 3 - r, kernel rows 8 - k -- so both run
+    // ONE instruction stream with the same register indices; the half enters through addresses only:
+    //   step ii = 0 .. 5 reads halo row (ih ? 11 - ii : ii) and multiplies it into accumulators r = 0 .. min(ii, 3)
+    //   with kernel-row slot k = ii - r (0 .. 5), slot k holding kernel row (ih ? 8 - k : k)
+    const int kys = ih ? -1 : 1, ky0 = ih ? 8 : 0;    // kernel row of slot k: ky0 + kys * k
+    h8 bh[6], bl[6];
+    // slot k of chunk g: a wave-uniform (scalar) pointer + this lane's 16 bytes
+    auto load_w = [&](int k, int g) {
+        unsigned lo = (unsigned)lane * 16u;
+        asm volatile("" : "+v"(lo));
+        const char* base = (const char*)wp + (size_t)((g * 9 + ky0 + kys * k) * 2) * 1024;
+        bh[k] = *(const h8*)(base + lo);
+        bl[k] = *(const h8*)(base + 1024 + lo);
+    };
+#pragma unroll
+    for (int k = 0; k < 6; ++k) load_w(k, 0);
+    barrier();                                        // chunk 0 is in LDS
+    // this lane's pixel fragments: column 32 ct + p, K half h; step ii at Ax + ii * xstep
+    const char* const Ax = lds + ((ih ? 11 : 0) * COLS + 32 * ct + p) * PSB + 16 * h;
+    const int xstep = ih ? -COLS * PSB : COLS * PSB;
 #pragma unroll 1
     for (int g = 0; g < 6; ++g) {
         const bool more = g + 1 < 6;
         if (more) load_stage(g + 1);
-        h8 xh[2][2], xl[2][2];                        // [buffer][mt]
+        h8 xh[2], xl[2];
+        xh[0] = *(const h8*)Ax;
+        xl[0] = *(const h8*)(Ax + 32);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            xh[0][mt] = *(const h8*)(Ax + mt * 32 * PSB);
-            xl[0][mt] = *(const h8*)(Ax + mt * 32 * PSB + 32);
-        }
-#pragma unroll
-        for (int ky = 0; ky < 9; ++ky) {
-            const int b = ky & 1;
-            if (ky + 1 < 9) {
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    xh[b ^ 1][mt] = *(const h8*)(Ax + ((ky + 1) * COLS + mt * 32) * PSB);
-                    xl[b ^ 1][mt] = *(const h8*)(Ax + ((ky + 1) * COLS + mt * 32) * PSB + 32);
-                }
+        for (int ii = 0; ii < 6; ++ii) {
+            const int b = ii & 1;
+            if (ii + 1 < 6) {
+                xh[b ^ 1] = *(const h8*)(Ax + (ii + 1) * xstep);
+                xl[b ^ 1] = *(const h8*)(Ax + (ii + 1) * xstep + 32);
             }
-            // the last three ky of a chunk also split the next chunk's pixels (four pieces each)
-            if (more && ky >= 6) {
+            // the last three steps of a chunk also split the next chunk's pixels (four pieces each)
+            if (more && ii >= 3) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) convert((ky - 6) * 4 + k);
+                for (int k = 0; k < 4; ++k) convert((ii - 3) * 4 + k);
             }
             __builtin_amdgcn_sched_barrier(0);
+            // term by term over the output rows this halo row reaches: independent accumulators back to back
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                acc[mt] = MFMA_H(xl[b][mt], bh[ky], acc[mt]);
-                acc[mt] = MFMA_H(xh[b][mt], bl[ky], acc[mt]);
-                acc[mt] = MFMA_H(xh[b][mt], bh[ky], acc[mt]);
-            }
-            if (more) {                               // this ky's weights of the next chunk
-                bh[ky] = wp[(((g + 1) * 9 + ky) * 2 + 0) * 64 + lane];
-                bl[ky] = wp[(((g + 1) * 9 + ky) * 2 + 1) * 64 + lane];
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+                for (int r = 0; r <= (ii < 3 ? ii : 3); ++r) {
+                    const int k = ii - r;
+                    acc[r] = term == 0 ? MFMA_H(xl[b], bh[k], acc[r])
+                           : term == 1 ? MFMA_H(xh[b], bl[k], acc[r]) : MFMA_H(xh[b], bh[k], acc[r]);
+                }
+            if (more) {                               // slots whose last product of this chunk was just issued: min(k + 3, 5) == ii
+#pragma unroll
+                for (int k = 0; k < 6; ++k)
+                    if ((k + 3 < 5 ? k + 3 : 5) == ii) load_w(k, g + 1);
             }
         }
         barrier();                                    // every wave is past its reads of chunk g
@@ -158,15 +178,22 @@ __global__ __launch_bounds__(NTHR, 1) void head_f32s_kernel(HeadArgs a)
         }
     }
 
-    // T -> LDS: Tl[row][x' 0..127][n 0..28]
-    float* Tl = (float*)lds + row * COLS * TS;
-    if (p < 27) {
+    // T -> LDS: Tl[row][x' 0..127][n 0..28] = (half 0) + (half 1), in that order
+    float* const T0 = (float*)lds;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+    for (int half = 0; half < 2; ++half) {
+        if (ih == half && p < 27) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) Tl[(64 * mh + 32 * mt + acc_row(r, h)) * TS + p] = acc[mt][r];
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float* t = T0 + (((ih ? 3 - r : r) * COLS) + 32 * ct + acc_row(e, h)) * TS + p;
+                    *t = half == 0 ? acc[r][e] : *t + acc[r][e];
+                }
+        }
+        barrier();
     }
-    barrier();
+    const float* Tl = T0 + row * COLS * TS;
     const int y = y0 + row;
     if (y < kOut) {
         float* yo = (float*)a.y + (size_t)n * 3 * kOut * kOut;
