@@ -130,7 +130,7 @@ struct ConvTile {
     int p[G];                   // output pixel of each 16-pixel group (may lie past M)
     unsigned vmask[G];          // bit t: tap t of that pixel lies inside the image (0 past M)
     const float* base[G];       // address of tap (0,0), channel 4*kq (may be out of image)
-    const char* wp;             // this lane's weight fragments of the tile's 64-channel block (16-byte fp32 or 8-byte bf16 units)
+    const char* wp;             // this lane's weight fragments of the tile's 64-channel block (16-byte units)
     int cb;
 };
 
@@ -138,17 +138,11 @@ struct ConvTile {
 // class grid OH x OW of the upper layer's dpre with the 1, 2 or 4 taps of a.taps (4-bit tap ids, real taps first, id 15 =
 // padding that reads zeros), and output pixel (oy, ox) of the class is pixel (2 oy + py, 2 ox + px) of the FH x FW image.
 //
-// BF (the GAN step's 16-bit arithmetic, train.py:148-150,166-168 under bf16 autocast): tensors stay fp32 in memory; a chunk's
-// activation fragment is rounded to bf16 when it is used and the weights come from a bf16 pack of the same layout (units
-// of four bf16), so a chunk is ONE v_mfma_f32_16x16x16_bf16 per accumulator instead of four v_mfma_f32_16x16x4_f32
-// (lane (l16, kq) supplies K = 4 kq .. 4 kq + 3 of the chunk either way), fp32 accumulation.
-template <int STRIDE, int G, bool PAR = false, bool BF = false>
+template <int STRIDE, int G, bool PAR = false>
 __global__ __launch_bounds__(256, G == 4 ? 1 : 2) void disc_conv_kernel(DiscConvArgs a, int OH, int OW, int M,
                                                                         int lg_nst, int ntiles)
 {
-    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    typedef short s16x4 __attribute__((ext_vector_type(4)));
-    using WFrag = std::conditional_t<BF, u32x2, f32x4>;
+    using WFrag = f32x4;
     constexpr int WU = sizeof(WFrag);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int l16 = lane & 15, kq = lane >> 4;
@@ -216,25 +210,13 @@ __global__ __launch_bounds__(256, G == 4 ? 1 : 2) void disc_conv_kernel(DiscConv
             for (int g = 0; g < G; ++g) acc[s][g] = f32x4{0.f, 0.f, 0.f, 0.f};
     };
     auto mma = [&](int ws, int xs) {
-        if constexpr (BF) {
 #pragma unroll
-            for (int g = 0; g < G; ++g) {
-                const f32x4 x = xb[xs][g];
-                const u32x2 xp = {pack2_bf16(x[0], x[1]), pack2_bf16(x[2], x[3])};
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
-                    acc[s][g] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, wb[ws][s]),
-                                                                          __builtin_bit_cast(s16x4, xp), acc[s][g], 0, 0, 0);
-            }
-        } else {
+            for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-#pragma unroll
-                    for (int g = 0; g < G; ++g)
-                        acc[s][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[ws][s][j], xb[xs][g][j], acc[s][g], 0, 0, 0);
-        }
+                for (int g = 0; g < G; ++g)
+                    acc[s][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[ws][s][j], xb[xs][g][j], acc[s][g], 0, 0, 0);
     };
 
     // One step = four chunks of tile T at step st; its prefetches reach into step sn of tile N (N is T
@@ -432,6 +414,7 @@ hipError_t launch_disc_stem(const DiscStemArgs& a, hipStream_t s)
 
 static hipError_t launch_conv_grid(const DiscConvArgs& a, int OH, int OW, long long M, bool par, hipStream_t s)
 {
+    if (a.bf16) return launch_disc_conv_bf16(a, OH, OW, par, s);       // bf16 products: the LDS-tiled kernel (srdisc_conv_bf16.hip)
     const int nst = a.Cin >> 6;                 // steps of 64 input channels per tap
     int lg = 0;
     while ((1 << lg) < nst) ++lg;
@@ -456,11 +439,7 @@ static hipError_t launch_conv_grid(const DiscConvArgs& a, int OH, int OW, long l
     const long long resident = (long long)cus * per_cu;
     const dim3 grid((unsigned)(blocks < resident ? blocks : resident)), block(256);
     const int ntiles = (int)blocks;
-#define DISC_LAUNCH(ST, GG, PP)                                                                                          \
-    do {                                                                                                                 \
-        if (a.bf16) hipLaunchKernelGGL((disc_conv_kernel<ST, GG, PP, true>), grid, block, lds_pad, s, a, OH, OW, (int)M, lg, ntiles); \
-        else hipLaunchKernelGGL((disc_conv_kernel<ST, GG, PP, false>), grid, block, lds_pad, s, a, OH, OW, (int)M, lg, ntiles);       \
-    } while (0)
+#define DISC_LAUNCH(ST, GG, PP) hipLaunchKernelGGL((disc_conv_kernel<ST, GG, PP>), grid, block, lds_pad, s, a, OH, OW, (int)M, lg, ntiles)
     if (par && wide) DISC_LAUNCH(1, 4, true);
     else if (par) DISC_LAUNCH(1, 2, true);
     else if (a.stride == 1 && wide) DISC_LAUNCH(1, 4, false);

@@ -22,14 +22,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // ---- weight packs made on the device from the live OIHW parameters ----------------------------------------------
-// mode 0: forward pack of pack_disc_conv (srdisc_api.cpp): float4 units [cout/64][tap 9][cin/16][s 4][lane 64]
-// mode 1: the same layout for the data-gradient conv: cin' = cout, cout' = cin, w'[co'][ci'][tap] = w[ci'][co'][8 - tap]
-// OutT = bf16_t: the same layout in bf16 (units of four = 8 bytes) for disc_conv_kernel<.., BF = true>
-__device__ __forceinline__ void put1(float* p, float v) { *p = v; }
-__device__ __forceinline__ void put1(bf16_t* p, float v) { p->bits = (unsigned short)(pack2_bf16(v, 0.f) & 0xffffu); }
-
-template <typename OutT>
-__global__ __launch_bounds__(256) void disc_pack_kernel(const float* __restrict__ w, OutT* __restrict__ out, int cin, int cout,
+// fp32 (disc_conv_kernel, srdisc_kernels.hip):
+//   mode 0: forward pack of pack_disc_conv (srdisc_api.cpp): float4 units [cout/64][tap 9][cin/16][s 4][lane 64]
+//   mode 1: the same layout for the data-gradient conv: cin' = cout, cout' = cin, w'[co'][ci'][tap] = w[ci'][co'][8 - tap]
+__global__ __launch_bounds__(256) void disc_pack_kernel(const float* __restrict__ w, float* __restrict__ out, int cin, int cout,
                                                         int mode, size_t total)
 {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;           // one packed float
@@ -46,15 +42,14 @@ __global__ __launch_bounds__(256) void disc_pack_kernel(const float* __restrict_
     const int m = lane & 15, kq = lane >> 4;
     const int co = 64 * cb + 16 * (m >> 2) + 4 * s + (m & 3);
     const int ci = 16 * ch + 4 * kq + j;
-    put1(out + idx, mode ? w[((size_t)ci * cin + co) * 9 + (8 - tap)] : w[((size_t)co * cin + ci) * 9 + tap]);
+    out[idx] = mode ? w[((size_t)ci * cin + co) * 9 + (8 - tap)] : w[((size_t)co * cin + ci) * 9 + tap];
 }
 
 // Packs of a stride-2 layer's data gradient, one per output parity class (py, px) (disc_conv_kernel<.., PAR>): input
 // pixel y = 2a + py receives dpre[a + dy] * w[ky] with ky = py + 1 - 2 dy, dy in {0} (py = 0) or {0, 1} (py = 1), and the
 // same along x: 1, 2, 2, 4 taps instead of the nine a zero-stuffed stride-1 conv would run.  Tap k of the class =
 // (ky', kx') = (1 + dy, 1 + dx), ky' outer; layout [cout'/64][k][cin'/16][s 4][lane 64] with cin' = cout, cout' = cin.
-template <typename OutT>
-__global__ __launch_bounds__(256) void disc_pack_par_kernel(const float* __restrict__ w, OutT* __restrict__ out, int cin, int cout,
+__global__ __launch_bounds__(256) void disc_pack_par_kernel(const float* __restrict__ w, float* __restrict__ out, int cin, int cout,
                                                             int py, int px, size_t total)
 {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -72,7 +67,40 @@ __global__ __launch_bounds__(256) void disc_pack_par_kernel(const float* __restr
     const int cip = 16 * ch + 4 * kq + j;                                // packed input channel = the layer's co
     const int dy = k / (px + 1), dx = k % (px + 1);
     const int ky = py + 1 - 2 * dy, kx = px + 1 - 2 * dx;
-    put1(out + idx, w[((size_t)cip * cin + cop) * 9 + ky * 3 + kx]);
+    out[idx] = w[((size_t)cip * cin + cop) * 9 + ky * 3 + kx];
+}
+
+// bf16 (disc_conv_lds_kernel, srdisc_conv_bf16.hip): the same three kinds of pack (kind 0 forward, 1 data gradient of a
+// stride-1 layer, 2 parity class (py, px) of a stride-2 layer's data gradient -- taps, flips and transposes as above) in
+// that kernel's layout: bf16 [cout'/BN][cin'/32][tap][k16 2][tile BN/32][lane 64][8], BN = 128 when cout' is a multiple of
+// 128, else 64; lane (r, h) of tile nt holds w'[co' = BN cb + 32 nt + r][ci' = 32 chunk + 16 k16 + 8 h + 0..7]: the MFMA
+// A-operand fragment of v_mfma_f32_32x32x16_bf16, one ds_read_b128 per lane.
+__global__ __launch_bounds__(256) void disc_pack_lds_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int cin, int cout,
+                                                            int kind, int py, int px, size_t total)
+{
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;           // one packed bf16
+    if (idx >= total) return;
+    const int pcin = kind ? cout : cin, pcout = kind ? cin : cout;
+    const int bn = pcout % 128 == 0 ? 128 : 64;
+    const int ntaps = kind == 2 ? (py + 1) * (px + 1) : 9;
+    const int e = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+    size_t unit = idx >> 9;
+    const int nt = (int)(unit % (bn / 32)); unit /= bn / 32;
+    const int k16 = (int)(unit & 1); unit >>= 1;
+    const int tap = (int)(unit % ntaps); unit /= ntaps;
+    const int chunk = (int)(unit % (pcin / 32));
+    const int cb = (int)(unit / (pcin / 32));
+    const int cop = bn * cb + 32 * nt + (lane & 31);
+    const int cip = 32 * chunk + 16 * k16 + 8 * (lane >> 5) + e;
+    float v;
+    if (kind == 0) v = w[((size_t)cop * cin + cip) * 9 + tap];
+    else if (kind == 1) v = w[((size_t)cip * cin + cop) * 9 + (8 - tap)];
+    else {
+        const int dy = tap / (px + 1), dx = tap % (px + 1);
+        const int ky = py + 1 - 2 * dy, kx = px + 1 - 2 * dx;
+        v = w[((size_t)cip * cin + cop) * 9 + ky * 3 + kx];
+    }
+    out[idx].bits = (unsigned short)(pack2_bf16(v, 0.f) & 0xffffu);
 }
 
 // stem pack [j 7][s 4][lane 64] (pack_disc_stem) and tail pack [tap 9][cin] (pack_disc_tail)
@@ -489,10 +517,10 @@ hipError_t launch_disc_pack(const float* w, float* out, int cin, int cout, int m
             const int py = c >> 1, px = c & 1;
             const size_t total = (size_t)(py + 1) * (px + 1) * cin * cout;
             if (bf16)
-                hipLaunchKernelGGL(disc_pack_par_kernel<bf16_t>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w,
-                                   (bf16_t*)out + off, cin, cout, py, px, total);
+                hipLaunchKernelGGL(disc_pack_lds_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w,
+                                   (bf16_t*)out + off, cin, cout, 2, py, px, total);
             else
-                hipLaunchKernelGGL(disc_pack_par_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, out + off,
+                hipLaunchKernelGGL(disc_pack_par_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, out + off,
                                    cin, cout, py, px, total);
             off += total;
         }
@@ -500,11 +528,10 @@ hipError_t launch_disc_pack(const float* w, float* out, int cin, int cout, int m
     }
     const size_t total = (size_t)cin * cout * 9;
     if (bf16)
-        hipLaunchKernelGGL(disc_pack_kernel<bf16_t>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, (bf16_t*)out, cin, cout,
-                           mode, total);
+        hipLaunchKernelGGL(disc_pack_lds_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, (bf16_t*)out, cin, cout,
+                           mode, 0, 0, total);
     else
-        hipLaunchKernelGGL(disc_pack_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, out, cin, cout, mode,
-                           total);
+        hipLaunchKernelGGL(disc_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, out, cin, cout, mode, total);
     return hipGetLastError();
 }
 

@@ -263,8 +263,8 @@ struct DiscConvArgs {          // conv Cin -> Cout (Cin % 16 == 0, Cout % 64 == 
     // stride-2 data gradient, one output parity class (disc_conv_kernel<.., PAR = true>)
     unsigned long long taps = 0;   // 4-bit tap ids (ky*3 + kx), real taps first, 15 = padding
     int ntaps = 0, nreal = 0, py = 0, px = 0, FH = 0, FW = 0;
-    int bf16 = 0;                  // 1: wpack holds bf16 units of four (launch_disc_pack with bf16 = true) and the products are
-                                   // bf16 x bf16 with fp32 accumulation; tensors stay fp32
+    int bf16 = 0;                  // 1: wpack is the bf16 pack of launch_disc_pack(.., bf16 = true) (the layout of
+                                   // srdisc_conv_bf16.hip) and the products are bf16 x bf16 with fp32 accumulation; tensors stay fp32
 };
 constexpr int kDiscZeroFloats = 512;
 struct DiscTailArgs {          // conv Cin -> 1, stride 1, pad 1, no activation
@@ -277,6 +277,8 @@ struct DiscTailArgs {          // conv Cin -> 1, stride 1, pad 1, no activation
 hipError_t launch_disc_stem(const DiscStemArgs& a, hipStream_t s);
 hipError_t launch_disc_conv(const DiscConvArgs& a, hipStream_t s);
 hipError_t launch_disc_dgrad2(const DiscConvArgs& a0, const float* wpack4, int fh, int fw, hipStream_t s);
+// the a.bf16 convs (srdisc_conv_bf16.hip): OH x OW = the grid the conv runs over, par: one parity class of a stride-2 data gradient
+hipError_t launch_disc_conv_bf16(const DiscConvArgs& a, int OH, int OW, bool par, hipStream_t s);
 hipError_t launch_disc_tail(const DiscTailArgs& a, hipStream_t s);
 hipError_t launch_ragan_loss(const float* real, const float* fake, size_t n_real, size_t n_fake,
                              float real_label, float fake_label, float* out2, hipStream_t s);
