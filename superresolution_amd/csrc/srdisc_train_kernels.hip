@@ -320,43 +320,55 @@ __global__ __launch_bounds__(256) void disc_stem_wgrad_reduce_kernel(const float
 }
 
 // dimg[n][ci][y][x] = sum_{tap, co} dpre[n][y - ky + 1][x - kx + 1][co] * w[co][ci][tap]  (gradient w.r.t. the image the
-// discriminator was fed: the path from the adversarial loss into the generator, train.py:168-174).  One lane per pixel,
-// the 64 x 27 weights in LDS (all lanes read the same word: broadcast).
+// discriminator was fed: the path from the adversarial loss into the generator, train.py:168-174).  Sixteen lanes per
+// pixel: lane q owns channels 4q .. 4q + 3 with its 9 x 4 x 3 weights in registers, so a pixel's 256 bytes of dpre are
+// one coalesced 16-byte load per lane and tap (one lane per pixel read them 256 bytes apart: 380 us at 64 images against
+// the 60 us the 256 MB take); the sixteen partial sums meet in four butterfly steps.  Workgroups walk the pixels with a
+// grid stride, so the weight registers are loaded once per ~30 pixels.
+constexpr int STEMD_BLOCKS = 2048;
 __global__ __launch_bounds__(256) void disc_stem_dgrad_kernel(const float* __restrict__ dpre, const float* __restrict__ w, int N, int H,
                                                               int W, float* __restrict__ dimg)
 {
-    __shared__ float ws[9][64][4];                                        // [tap][co][ci (3 used)]
-    for (int k = threadIdx.x; k < 64 * 27; k += 256) {
-        const int co = k / 27, r = k % 27, ci = r / 9, tap = r % 9;       // w is (64, 3, 3, 3) OIHW
-        ws[tap][co][ci] = w[k];
-    }
-    __syncthreads();
+    const int q = threadIdx.x & 15;
+    float wr[9][4][3];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci) wr[tap][e][ci] = w[((4 * q + e) * 3 + ci) * 9 + tap];     // w is (64, 3, 3, 3) OIHW
     const long long total = (long long)N * H * W;
-    const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (p >= total) return;
     const int hw = H * W;
-    const int n = (int)(p / hw), r = (int)(p - (long long)n * hw);
-    const int y = r / W, x = r - y * W;
-    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
-    for (int tap = 0; tap < 9; ++tap) {
-        const int sy = y - tap / 3 + 1, sx = x - tap % 3 + 1;
-        if ((unsigned)sy >= (unsigned)H || (unsigned)sx >= (unsigned)W) continue;
-        const float* d = dpre + (((size_t)n * H + sy) * W + sx) * 64;
-#pragma unroll 4
-        for (int c = 0; c < 64; c += 4) {
-            const f32x4 dv = *(const f32x4*)(d + c);
+    const long long stride = (long long)gridDim.x * 16;
+    for (long long p = (long long)blockIdx.x * 16 + (threadIdx.x >> 4); p < total; p += stride) {
+        const int n = (int)(p / hw), r = (int)(p - (long long)n * hw);
+        const int y = r / W, x = r - y * W;
+        float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int sy = y - tap / 3 + 1, sx = x - tap % 3 + 1;
+            if ((unsigned)sy >= (unsigned)H || (unsigned)sx >= (unsigned)W) continue;
+            const f32x4 dv = *(const f32x4*)(dpre + (((size_t)n * H + sy) * W + sx) * 64 + 4 * q);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                g0 = fmaf(dv[e], ws[tap][c + e][0], g0);
-                g1 = fmaf(dv[e], ws[tap][c + e][1], g1);
-                g2 = fmaf(dv[e], ws[tap][c + e][2], g2);
+                g0 = fmaf(dv[e], wr[tap][e][0], g0);
+                g1 = fmaf(dv[e], wr[tap][e][1], g1);
+                g2 = fmaf(dv[e], wr[tap][e][2], g2);
             }
         }
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) {
+            g0 += __shfl_xor(g0, o);
+            g1 += __shfl_xor(g1, o);
+            g2 += __shfl_xor(g2, o);
+        }
+        if (q == 0) {
+            float* o = dimg + (size_t)n * 3 * hw + r;
+            o[0] = g0;
+            o[hw] = g1;
+            o[2 * hw] = g2;
+        }
     }
-    float* o = dimg + (size_t)n * 3 * hw + r;
-    o[0] = g0;
-    o[hw] = g1;
-    o[2 * hw] = g2;
 }
 
 // ---- tail (Cin -> 1, no activation, Discriminator.py:37) backward ---------------------------------------------------------
@@ -589,7 +601,10 @@ hipError_t launch_disc_stem_wgrad(const float* img, const float* dpre, int n, in
 hipError_t launch_disc_stem_dgrad(const float* dpre, const float* w, int n, int h, int wd, float* dimg, hipStream_t s)
 {
     const long long total = (long long)n * h * wd;
-    hipLaunchKernelGGL(disc_stem_dgrad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dpre, w, n, h, wd, dimg);
+    if (total <= 0) return hipSuccess;
+    const long long want = (total + 15) / 16;
+    hipLaunchKernelGGL(disc_stem_dgrad_kernel, dim3((unsigned)(want < STEMD_BLOCKS ? want : STEMD_BLOCKS)), dim3(256), 0, s, dpre, w, n,
+                       h, wd, dimg);
     return hipGetLastError();
 }
 

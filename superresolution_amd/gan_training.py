@@ -89,16 +89,27 @@ class DiscriminatorGrad:
         # accumulation; tensors stay fp32, the stem, the tail and every weight gradient keep fp32 products).  A forward
         # remembers its setting for its backward
         self.products = "fp32"
+        self._packs = {}
 
     def _pack(self, conv: torch.nn.Conv2d, mode: int, bf16: bool = False) -> torch.Tensor:
-        w = conv.weight.detach().contiguous()
+        """Kernel-side image of a conv's live weights (made on the device).  Kept until the parameter changes: the
+        discriminator is updated every third iteration only (config.py:21), and a generator half-step packs the same
+        weights its discriminator half-step just used.  A change is an in-place update (the version counter every torch
+        optimizer and FlatAdamW bump) or a new storage."""
+        p = conv.weight
+        bf16 = bf16 and mode in (0, 1, 4)
+        key, tag = (id(conv), mode, bf16), (p._version, p.data_ptr())
+        hit = self._packs.get(key)
+        if hit is not None and hit[0] == tag:
+            return hit[1]
+        w = p.detach().contiguous()
         cout, cin = w.shape[0], w.shape[1]
         numel = {0: w.numel(), 1: w.numel(), 2: 7 * 4 * 64, 3: 9 * cin, 4: w.numel()}[mode]
-        bf16 = bf16 and mode in (0, 1, 4)
         out = torch.empty(numel, dtype=torch.bfloat16 if bf16 else torch.float32, device=w.device)
         fn = _lib.lib().srdisc_pack_bf16 if bf16 else _lib.lib().srdisc_pack
         with torch.cuda.device(w.device):
             _lib.check(fn(w.data_ptr(), cin, cout, mode, out.data_ptr(), _stream(w)))
+        self._packs[key] = (tag, out)
         return out
 
     # -- forward --------------------------------------------------------------------------------------------------------
