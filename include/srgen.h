@@ -478,13 +478,19 @@ SRGEN_API int srdisc_tail_bwd(const float* dlogits, const float* w_oihw, const f
 /* 16-bit products for the discriminator's 64..512-channel convs (forward and data gradient): what torch.autocast(bfloat16)
  * gives them at /root/reference/train.py:150,168.  Tensors stay fp32 in memory; an activation fragment is rounded to bf16
  * when it is multiplied, the weights come from a bf16 pack (srdisc_pack_bf16: modes 0, 1, 4 of srdisc_pack, 2 bytes per
- * weight), accumulation is fp32.  The 3-channel stem, the 1-channel tail and every weight gradient keep fp32 products.
+ * weight), accumulation is fp32.  The 3-channel stem and the 1-channel tail keep fp32 products.
  * Arguments as srdisc_pack / srdisc_conv_nhwc / srdisc_conv_dgrad2. */
 SRGEN_API int srdisc_pack_bf16(const float* w_oihw, int cin, int cout, int mode, void* out, void* stream);
 SRGEN_API int srdisc_conv_nhwc_bf16p(const float* in, const void* wpack_bf16, const float* bias, const float* mask, float* out,
                                      int n, int h, int w, int cin, int cout, int stride, float slope, void* stream);
 SRGEN_API int srdisc_conv_dgrad2_bf16p(const float* dpre, const void* wpack4_bf16, const float* mask, float* out, int n, int h,
                                        int w, int cin, int cout, float slope, void* stream);
+/* The weight gradient of such a layer on bf16 products (what autograd computes for these convs inside the autocast of
+ * /root/reference/train.py:148-152: both operands of the gradient GEMM rounded to bf16 where they are multiplied, fp32
+ * accumulation, fp32 tensors and results).  Arguments, result layout and summation discipline (fixed order) as
+ * srdisc_conv_wgrad; scratch: srdisc_conv_wgrad_scratch_bytes serves both. */
+SRGEN_API int srdisc_conv_wgrad_bf16p(const float* in, const float* dpre, int n, int h, int w, int cin, int cout, int stride,
+                                      float* dw, float* dbias, void* scratch, size_t scratch_bytes, void* stream);
 /* Replaces: the gradient of RelativisticAverageLoss (Discriminator.py:60-72) w.r.t. its logits, times `scale`:
  * targets (real_label, fake_label) = discriminator_loss, (0, 1) = generator_loss.  dreal may be NULL (the generator
  * step detaches the real logits, train.py:169). */

@@ -138,6 +138,8 @@ def lib() -> ctypes.CDLL:
     L.srdisc_conv_dgrad2.restype = i
     L.srdisc_conv_wgrad_scratch_bytes.argtypes = [i, i, i, i, i, psz]
     L.srdisc_conv_wgrad.argtypes = [vp, vp, i, i, i, i, i, i, vp, vp, vp, sz, vp]
+    L.srdisc_conv_wgrad_bf16p.argtypes = L.srdisc_conv_wgrad.argtypes
+    L.srdisc_conv_wgrad_bf16p.restype = i
     L.srdisc_stem_wgrad_scratch_bytes.argtypes = [psz]
     L.srdisc_stem_wgrad.argtypes = [vp, vp, i, i, i, vp, vp, vp, sz, vp]
     L.srdisc_stem_dgrad.argtypes = [vp, vp, i, i, i, vp, vp]

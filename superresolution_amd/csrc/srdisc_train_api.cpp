@@ -156,7 +156,8 @@ int srdisc_conv_wgrad_scratch_bytes(int n, int h, int cin, int cout, int stride,
 {
     if (!bytes || n <= 0 || h < 1 || (stride != 1 && stride != 2)) return fail(SRGEN_E_INVALID, "bad argument");
     if (int rc = check_channels(cin, cout)) return rc;
-    *bytes = (disc_wgrad_scratch_bytes(n, (h - 1) / stride + 1, cin, cout) + 255) & ~(size_t)255;
+    const size_t a = disc_wgrad_scratch_bytes(n, (h - 1) / stride + 1, cin, cout), b = disc_wgrad_bf16_scratch_bytes(cin, cout);
+    *bytes = ((a > b ? a : b) + 255) & ~(size_t)255;         // serves srdisc_conv_wgrad and srdisc_conv_wgrad_bf16p
     return SRGEN_OK;
 }
 
@@ -171,6 +172,20 @@ int srdisc_conv_wgrad(const float* in, const float* dpre, int n, int h, int w, i
     const size_t need = disc_wgrad_scratch_bytes(n, (h - 1) / stride + 1, cin, cout);
     if (scratch_bytes < need) return fail(SRGEN_E_WORKSPACE, "scratch of %zu bytes, %zu needed", scratch_bytes, need);
     HIP_TRY(launch_disc_wgrad(in, dpre, n, h, w, cin, cout, stride, dw, dbias, scratch, (hipStream_t)stream));
+    return SRGEN_OK;
+}
+
+int srdisc_conv_wgrad_bf16p(const float* in, const float* dpre, int n, int h, int w, int cin, int cout, int stride, float* dw, float* dbias,
+                            void* scratch, size_t scratch_bytes, void* stream)
+{
+    if (!in || !dpre || !dw || !scratch) return fail(SRGEN_E_INVALID, "NULL argument");
+    if (int rc = check_img(n, h, w)) return rc;
+    if (int rc = check_channels(cin, cout)) return rc;
+    if (stride != 1 && stride != 2) return fail(SRGEN_E_INVALID, "stride %d", stride);
+    if (!aligned16(in) || !aligned16(dpre) || !aligned16(scratch)) return fail(SRGEN_E_INVALID, "operands must be 16-byte aligned");
+    const size_t need = disc_wgrad_bf16_scratch_bytes(cin, cout);
+    if (scratch_bytes < need) return fail(SRGEN_E_WORKSPACE, "scratch of %zu bytes, %zu needed", scratch_bytes, need);
+    HIP_TRY(launch_disc_wgrad_bf16(in, dpre, n, h, w, cin, cout, stride, dw, dbias, scratch, (hipStream_t)stream));
     return SRGEN_OK;
 }
 

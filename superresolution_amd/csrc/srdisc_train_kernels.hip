@@ -583,6 +583,14 @@ hipError_t launch_disc_wgrad(const float* in, const float* dpre, int n, int h, i
     return hipGetLastError();
 }
 
+hipError_t launch_disc_wgrad_reduce(const float* slab, const float* bias_slab, int slices, int cin, int cout, float* dw, float* dbias,
+                                    hipStream_t s)
+{
+    hipLaunchKernelGGL(disc_wgrad_reduce_kernel, dim3((unsigned)((size_t)9 * cin * cout / 64)), dim3(256), 0, s, slab, bias_slab, slices,
+                       cin, cout, dw, dbias);
+    return hipGetLastError();
+}
+
 size_t disc_stem_wgrad_scratch_bytes() { return ((size_t)STEMW_WGS * 4 * 2048 + (size_t)STEMW_WGS * 4 * 64) * sizeof(float); }
 
 hipError_t launch_disc_stem_wgrad(const float* img, const float* dpre, int n, int h, int w, float* dw, float* dbias, void* scratch,

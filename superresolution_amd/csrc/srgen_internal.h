@@ -287,6 +287,12 @@ hipError_t launch_ragan_loss(const float* real, const float* fake, size_t n_real
 // packs from live OIHW weights on the device: mode 0 forward conv, 1 data-gradient conv, 2 stem, 3 tail
 hipError_t launch_disc_pack(const float* w, float* out, int cin, int cout, int mode, hipStream_t s, bool bf16 = false);
 size_t disc_wgrad_scratch_bytes(int n, int oh, int cin, int cout);
+hipError_t launch_disc_wgrad_reduce(const float* slab, const float* bias_slab, int slices, int cin, int cout, float* dw, float* dbias,
+                                    hipStream_t s);
+// bf16 products (srdisc_wgrad_bf16.hip): same operands and results, its own slice count
+size_t disc_wgrad_bf16_scratch_bytes(int cin, int cout);
+hipError_t launch_disc_wgrad_bf16(const float* in, const float* dpre, int n, int h, int w, int cin, int cout, int stride, float* dw,
+                                  float* dbias, void* scratch, hipStream_t s);
 hipError_t launch_disc_wgrad(const float* in, const float* dpre, int n, int h, int w, int cin, int cout, int stride, float* dw,
                              float* dbias, void* scratch, hipStream_t s);
 size_t disc_stem_wgrad_scratch_bytes();

@@ -86,8 +86,8 @@ class DiscriminatorGrad:
         self.strides = [1, 2, 1, 2, 1, 2, 1, 2, 1, 1]
         # products of the eight 64..512-channel convs (forward and data gradient): "fp32" (exact-fp32 MFMA) or "bf16" (what
         # torch.autocast(bfloat16) gives them at train.py:150,168: operands rounded to bf16 where they are multiplied, fp32
-        # accumulation; tensors stay fp32, the stem, the tail and every weight gradient keep fp32 products).  A forward
-        # remembers its setting for its backward
+        # accumulation, in the forward, the data gradient and the weight gradient; tensors stay fp32, the stem and the tail
+        # keep fp32 products).  A forward remembers its setting for its backward
         self.products = "fp32"
         self._packs = {}
 
@@ -203,8 +203,9 @@ class DiscriminatorGrad:
                     _lib.check(L.srdisc_conv_wgrad_scratch_bytes(n, ih, cin, cout, st, ctypes.byref(need)))
                     scratch = ws.get("disc_wgrad", need.value)
                     dw, db = torch.empty_like(conv.weight), torch.empty_like(conv.bias)
-                    _lib.check(L.srdisc_conv_wgrad(acts[i - 1].data_ptr(), dpre.data_ptr(), n, ih, iw, cin, cout, st, dw.data_ptr(),
-                                                   db.data_ptr(), scratch.data_ptr(), scratch.numel(), s))
+                    wgrad_fn = L.srdisc_conv_wgrad_bf16p if b16 else L.srdisc_conv_wgrad
+                    _lib.check(wgrad_fn(acts[i - 1].data_ptr(), dpre.data_ptr(), n, ih, iw, cin, cout, st, dw.data_ptr(),
+                                        db.data_ptr(), scratch.data_ptr(), scratch.numel(), s))
                     put(conv, dw, db)
                 if i == 1 and not want_wgrad and not want_dimg:
                     break

@@ -74,7 +74,7 @@ def _rb(t):
 def test_discriminator_bf16_products_vs_torch_emulation(shape):
     """DiscriminatorGrad.products = "bf16" (what autocast gives the 64..512-channel convs at train.py:150,168): tensors
     stay fp32, a conv's activation (forward) or gradient (data gradient) operand and its weights are rounded to bf16 where
-    they are multiplied, accumulation is fp32; the stem, the tail and every weight gradient keep fp32 products.
+    they are multiplied, accumulation is fp32 (forward, data gradient, weight gradient); the stem and the tail keep fp32 products.
     (a) every layer's forward and data gradient against exactly that arithmetic written with stock torch ops on the CPU, fed
         the SAME operands (products of bf16 numbers are exact in fp32: what is left is summation order; bar 2e-5 of max --
         chained through the network instead, two correct implementations drift apart to the bf16 rounding noise itself,
@@ -159,6 +159,46 @@ def test_discriminator_bf16_products_vs_torch_emulation(shape):
         ra, ca = rel_cos(wa.grad, w_.grad)
         print(f"  layer {i} weight gradient vs fp32: rel {r:.2e}, cosine {c:.6f}   (torch autocast: rel {ra:.2e}, cosine {ca:.6f})")
         assert r <= 2.0 * ra, (i, r, ra)
+
+
+@pytest.mark.parametrize("cfg", [(2, 37, 53, 64, 64, 2), (3, 19, 27, 64, 128, 1), (2, 19, 27, 128, 128, 2), (2, 16, 16, 256, 512, 1),
+                                 (3, 16, 16, 512, 512, 2), (5, 8, 8, 512, 256, 1), (1, 5, 7, 64, 64, 1), (4, 125, 125, 64, 64, 2)])
+def test_discriminator_wgrad_bf16_products_vs_torch_emulation(cfg):
+    """srdisc_conv_wgrad_bf16p (the weight gradient inside train.py:148-152's autocast): both operands rounded to bf16 where
+    they are multiplied, fp32 accumulation -- against exactly that arithmetic in fp64 with stock torch ops on the CPU, on
+    the SAME operands (products of bf16 numbers are exact: what is left is fp32 summation over up to 16k pixels; bar 2e-5 of
+    max); the bias gradient is the fp32 sum of dpre.  Shapes: both strides, ragged grids, an 8-wide grid, tiles that hang
+    over the image, slices that end inside an image."""
+    import ctypes
+    from superresolution_amd import _lib
+    n, h, w, cin, cout, st = cfg
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(3)
+    oh, ow = (h - 1) // st + 1, (w - 1) // st + 1
+    x = torch.rand((n, h, w, cin), generator=g) - 0.3
+    dpre = torch.randn((n, oh, ow, cout), generator=g) * 1e-3
+    xd, dd = x.cuda(), dpre.cuda()
+    dw = torch.empty((cout, cin, 3, 3), device="cuda")
+    db = torch.empty(cout, device="cuda")
+    need = ctypes.c_size_t()
+    _lib.check(L.srdisc_conv_wgrad_scratch_bytes(n, h, cin, cout, st, ctypes.byref(need)))
+    scratch = torch.empty(need.value, dtype=torch.uint8, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    _lib.check(L.srdisc_conv_wgrad_bf16p(xd.data_ptr(), dd.data_ptr(), n, h, w, cin, cout, st, dw.data_ptr(), db.data_ptr(),
+                                         scratch.data_ptr(), scratch.numel(), s))
+    xr = _rb(x).permute(0, 3, 1, 2).double()
+    dr = _rb(dpre).permute(0, 3, 1, 2).double()
+    ref = torch.nn.grad.conv2d_weight(xr, (cout, cin, 3, 3), dr, stride=st, padding=1)
+    e = max_rel(dw.cpu().numpy(), ref.numpy())
+    eb = max_rel(db.cpu().numpy(), dpre.double().sum(dim=(0, 1, 2)).numpy())
+    print(f"  wgrad bf16 products {cfg}: {e:.2e}, bias {eb:.2e}")
+    assert e <= 2e-5 and eb <= 2e-5, (cfg, e, eb)
+    # the fp32-product operator on the same operands: a bf16-sized distance, and not zero (the kernels are different ones)
+    dw32 = torch.empty_like(dw)
+    _lib.check(L.srdisc_conv_wgrad(xd.data_ptr(), dd.data_ptr(), n, h, w, cin, cout, st, dw32.data_ptr(), db.data_ptr(),
+                                   scratch.data_ptr(), scratch.numel(), s))
+    d = max_rel(dw.cpu().numpy(), dw32.cpu().numpy())
+    assert 1e-6 <= d <= 3e-2, d
 
 
 def test_ragan_loss_grad_vs_torch_autograd():

@@ -73,8 +73,9 @@ def main():
         nb = ctypes.c_size_t()
         _lib.check(L.srdisc_conv_wgrad_scratch_bytes(n, h, cin, cout, st, ctypes.byref(nb)))
         scratch = torch.empty(nb.value, dtype=torch.uint8, device=dev)
-        t_w = timed(lambda: _lib.check(L.srdisc_conv_wgrad(x.data_ptr(), dpre.data_ptr(), n, h, h, cin, cout, st, dw.data_ptr(),
-                                                           db.data_ptr(), scratch.data_ptr(), nb.value, s)))
+        wg = L.srdisc_conv_wgrad_bf16p if b16 else L.srdisc_conv_wgrad
+        t_w = timed(lambda: _lib.check(wg(x.data_ptr(), dpre.data_ptr(), n, h, h, cin, cout, st, dw.data_ptr(),
+                                          db.data_ptr(), scratch.data_ptr(), nb.value, s)))
         tot["fwd"] += t_f
         tot["dgrad"] += t_d
         tot["wgrad"] += t_w
