@@ -320,16 +320,17 @@ __global__ __launch_bounds__(256) void disc_stem_wgrad_reduce_kernel(const float
 }
 
 // dimg[n][ci][y][x] = sum_{tap, co} dpre[n][y - ky + 1][x - kx + 1][co] * w[co][ci][tap]  (gradient w.r.t. the image the
-// discriminator was fed: the path from the adversarial loss into the generator, train.py:168-174).  Sixteen lanes per
-// pixel: lane q owns channels 4q .. 4q + 3 with its 9 x 4 x 3 weights in registers, so a pixel's 256 bytes of dpre are
-// one coalesced 16-byte load per lane and tap (one lane per pixel read them 256 bytes apart: 380 us at 64 images against
-// the 60 us the 256 MB take); the sixteen partial sums meet in four butterfly steps.  Workgroups walk the pixels with a
-// grid stride, so the weight registers are loaded once per ~30 pixels.
-constexpr int STEMD_BLOCKS = 2048;
+// discriminator was fed: the path from the adversarial loss into the generator, train.py:168-174).  Workgroup = 8 x 16
+// pixels: the 10 x 18 halo of dpre (64 channels, fp32) goes to LDS once (zero outside the image) -- read from memory, the nine
+// taps fetched the tensor nine times from L2 (0.34 ms at 64 images for a 256 MB tensor).  Sixteen lanes per pixel: lane q
+// owns channels 4q .. 4q + 3 with its 9 x 4 x 3 weights in registers, a tap is one 16-byte LDS read and twelve FMAs per
+// lane, the sixteen partial sums meet in four butterfly steps.  Pixel pitch 272 B (17 x 16 B).
+constexpr int SD_TH = 8, SD_TW = 16, SD_HR = SD_TH + 2, SD_HC = SD_TW + 2, SD_PITCH = 272;
 __global__ __launch_bounds__(256) void disc_stem_dgrad_kernel(const float* __restrict__ dpre, const float* __restrict__ w, int N, int H,
-                                                              int W, float* __restrict__ dimg)
+                                                              int W, int tiles_x, int tiles_y, float* __restrict__ dimg)
 {
-    const int q = threadIdx.x & 15;
+    __shared__ __attribute__((aligned(16))) char tile[SD_HR * SD_HC * SD_PITCH];       // 48,960 B
+    const int q = threadIdx.x & 15, ps = threadIdx.x >> 4;
     float wr[9][4][3];
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
@@ -337,18 +338,33 @@ __global__ __launch_bounds__(256) void disc_stem_dgrad_kernel(const float* __res
         for (int e = 0; e < 4; ++e)
 #pragma unroll
             for (int ci = 0; ci < 3; ++ci) wr[tap][e][ci] = w[((4 * q + e) * 3 + ci) * 9 + tap];     // w is (64, 3, 3, 3) OIHW
-    const long long total = (long long)N * H * W;
+    int bid = blockIdx.x;
+    const int txb = bid % tiles_x;
+    bid /= tiles_x;
+    const int tyb = bid % tiles_y, n = bid / tiles_y;
+    const int y0 = tyb * SD_TH, x0 = txb * SD_TW;
+    const float* src = dpre + (size_t)n * H * W * 64 + 4 * q;
+#pragma unroll
+    for (int k = 0; k < (SD_HR * SD_HC + 15) / 16; ++k) {
+        const int px = ps + 16 * k;
+        if (px < SD_HR * SD_HC) {
+            const int hr = px / SD_HC, hc = px - hr * SD_HC;
+            const int gy = y0 - 1 + hr, gx = x0 - 1 + hc;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) v = *(const f32x4*)(src + ((size_t)gy * W + gx) * 64);
+            *(f32x4*)(tile + px * SD_PITCH + q * 16) = v;
+        }
+    }
+    __syncthreads();
     const int hw = H * W;
-    const long long stride = (long long)gridDim.x * 16;
-    for (long long p = (long long)blockIdx.x * 16 + (threadIdx.x >> 4); p < total; p += stride) {
-        const int n = (int)(p / hw), r = (int)(p - (long long)n * hw);
-        const int y = r / W, x = r - y * W;
+#pragma unroll 2
+    for (int pass = 0; pass < SD_TH * SD_TW / 16; ++pass) {
+        const int p = ps + 16 * pass, ty = p >> 4, tx = p & 15;
         float g0 = 0.f, g1 = 0.f, g2 = 0.f;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            const int sy = y - tap / 3 + 1, sx = x - tap % 3 + 1;
-            if ((unsigned)sy >= (unsigned)H || (unsigned)sx >= (unsigned)W) continue;
-            const f32x4 dv = *(const f32x4*)(dpre + (((size_t)n * H + sy) * W + sx) * 64 + 4 * q);
+            const int hr = ty - tap / 3 + 2, hc = tx - tap % 3 + 2;          // source pixel (y - ky + 1, x - kx + 1) in halo coordinates
+            const f32x4 dv = *(const f32x4*)(tile + (hr * SD_HC + hc) * SD_PITCH + q * 16);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 g0 = fmaf(dv[e], wr[tap][e][0], g0);
@@ -362,8 +378,9 @@ __global__ __launch_bounds__(256) void disc_stem_dgrad_kernel(const float* __res
             g1 += __shfl_xor(g1, o);
             g2 += __shfl_xor(g2, o);
         }
-        if (q == 0) {
-            float* o = dimg + (size_t)n * 3 * hw + r;
+        const int y = y0 + ty, x = x0 + tx;
+        if (q == 0 && y < H && x < W) {
+            float* o = dimg + (size_t)n * 3 * hw + (size_t)y * W + x;
             o[0] = g0;
             o[hw] = g1;
             o[2 * hw] = g2;
@@ -608,11 +625,11 @@ hipError_t launch_disc_stem_wgrad(const float* img, const float* dpre, int n, in
 
 hipError_t launch_disc_stem_dgrad(const float* dpre, const float* w, int n, int h, int wd, float* dimg, hipStream_t s)
 {
-    const long long total = (long long)n * h * wd;
-    if (total <= 0) return hipSuccess;
-    const long long want = (total + 15) / 16;
-    hipLaunchKernelGGL(disc_stem_dgrad_kernel, dim3((unsigned)(want < STEMD_BLOCKS ? want : STEMD_BLOCKS)), dim3(256), 0, s, dpre, w, n,
-                       h, wd, dimg);
+    if (n <= 0 || h <= 0 || wd <= 0) return hipSuccess;
+    const int tiles_x = (wd + SD_TW - 1) / SD_TW, tiles_y = (h + SD_TH - 1) / SD_TH;
+    const long long blocks = (long long)n * tiles_x * tiles_y;
+    if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(disc_stem_dgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dpre, w, n, h, wd, tiles_x, tiles_y, dimg);
     return hipGetLastError();
 }
 
