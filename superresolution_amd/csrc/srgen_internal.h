@@ -383,6 +383,10 @@ hipError_t launch_prelu_scalar_bwd_bf16(const void* x, const void* dy, const voi
                                         float* dslope, size_t numel, void* scratch, hipStream_t s);
 hipError_t launch_conv9x9_c3_wgrad_bf16(const void* act, const float* img, int n, int ah, int aw, int ih, int iw, int flip, float* r,
                                         float* dbias, void* scratch, hipStream_t s);
+hipError_t launch_conv9x9_c3_wgrad_reduce(const float* slab, const float* bias_slab, int slices, float* r, float* dbias, hipStream_t s);
+// rows of 64 | 128 pixels on v_mfma_f32_32x32x16_bf16 (srgen_wgrad9_bf16.hip); scratch as conv9x9_c3_wgrad_scratch_bytes, slices <= its count
+hipError_t launch_conv9x9_c3_wgrad_bf16_mfma(const void* act, const float* img, int n, int ah, int aw, int ih, int iw, int flip, float* r,
+                                             float* dbias, void* scratch, int slices, hipStream_t s);
 hipError_t launch_chan_attn_bwd_bf16(const void* x, const void* dy, const float* pool_partial, const float* scale, int n, int hw,
                                      const float* w1, const float* b1, const float* w2, const float* b2, void* dx, float* dw1,
                                      float* db1, float* dw2, float* db2, void* scratch, hipStream_t s);

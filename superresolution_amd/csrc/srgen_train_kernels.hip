@@ -1517,9 +1517,23 @@ hipError_t launch_conv9x9_c3_wgrad(const float* act, const float* img, int n, in
     return conv9x9_c3_wgrad_t<float>(act, img, n, ah, aw, ih, iw, flip, r, dbias, scratch, s);
 }
 
+hipError_t launch_conv9x9_c3_wgrad_reduce(const float* slab, const float* bias_slab, int slices, float* r, float* dbias, hipStream_t s)
+{
+    hipLaunchKernelGGL(conv9x9_c3_wgrad_reduce_kernel, dim3(96 * 256 / 64), dim3(1024), 0, s, slab, bias_slab, slices, r, dbias);
+    return hipGetLastError();
+}
+
 hipError_t launch_conv9x9_c3_wgrad_bf16(const void* act, const float* img, int n, int ah, int aw, int ih, int iw, int flip, float* r,
                                         float* dbias, void* scratch, hipStream_t s)
 {
+    // rows of 64 or 128 pixels (the generator's stem and head): the bf16 matrix instruction (srgen_wgrad9_bf16.hip), one
+    // workgroup per CU; any other width: the fp32 matrix instruction on the operands as they are
+    if (aw == 64 || aw == 128) {
+        const int total_rows = n * ah;
+        const int cap = wgrad9_slices(total_rows);                       // what the scratch was sized for
+        const int slices = cap < 256 ? cap : 256;                        // (one workgroup per CU)
+        return launch_conv9x9_c3_wgrad_bf16_mfma(act, img, n, ah, aw, ih, iw, flip, r, dbias, scratch, slices, s);
+    }
     return conv9x9_c3_wgrad_t<bf16_t>((const bf16_t*)act, img, n, ah, aw, ih, iw, flip, r, dbias, scratch, s);
 }
 

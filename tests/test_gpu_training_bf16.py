@@ -152,8 +152,11 @@ def test_stem_and_head_bf16_vs_fp32():
     _close_rounded(x1b, x1f, "stem forward")
     # stem weight gradient: bf16 activation gradient against the fp32 image
     db_, df = _b((_nhwc(_hash_tensor(41, "d", (4, 96, 64, 64))) * 2.0 ** -18).cuda())
-    rb_, bb = T.conv9x9_c3_wgrad(db_, lr, ws, flip=False, want_bias=True)
-    rf, bf = T.conv9x9_c3_wgrad(df, lr, ws, flip=False, want_bias=True)
+    # (the 16-bit operator multiplies bf16 x bf16 -- inside autocast the conv's image operand is bf16 too -- so both sides get
+    # an image that is representable in bf16)
+    lrr = lr.to(torch.bfloat16).float().contiguous()
+    rb_, bb = T.conv9x9_c3_wgrad(db_, lrr, ws, flip=False, want_bias=True)
+    rf, bf = T.conv9x9_c3_wgrad(df, lrr, ws, flip=False, want_bias=True)
     _close_sums(rb_, rf, "stem weight gradient")
     _close_sums(bb, bf, "stem bias gradient")
     # head: bf16 (n, 128, 128, 96) -> fp32 image; its weights are rounded to bf16 by the 16-bit step, so compare on those
@@ -167,6 +170,34 @@ def test_stem_and_head_bf16_vs_fp32():
     whm = g.output[2].weight.detach().permute(0, 2, 3, 1).reshape(243, 96).contiguous()
     _close_rounded(T.conv9x9_c3(dsr, whm, None, 128, True, out_dtype=torch.bfloat16), T.conv9x9_c3(dsr, whm, None, 128, True),
                    "head data gradient")
+
+
+@pytest.mark.parametrize("flip,n", [(False, 3), (True, 3), (True, 1)])
+def test_conv9x9_weight_gradient_bf16_mfma_vs_torch_emulation(flip, n):
+    """srgen_conv9x9_c3_wgrad_bf16 on rows of 64 / 128 pixels (srgen_wgrad9_bf16.hip: bf16 MFMA, eight shifted copies of
+    every image row): against the gradient GEMM written with stock torch ops in fp64 on the CPU, both operands rounded to bf16
+    (products exact, fp32 accumulation over up to 49k pixels: bar 2e-5 of max).  flip = False: the stem (Generator.py:50; act
+    = d x1 at 64 x 64, img = the lr input); flip = True: the head (:71; act = its 128 x 128 input, img = d out at 125 x 125,
+    the crop's zero rows / columns outside).  n = 3: slices that start in the middle of an image."""
+    from superresolution_amd import training as T
+    ws = T.Workspace(torch.device("cuda"))
+    hw, ih = (128, 125) if flip else (64, 64)
+    act_b, act_f = _b(_nhwc(_hash_tensor(51, "a9", (n, 96, hw, hw))).cuda())
+    img = (_hash_tensor(52, "i9", (n, 3, ih, ih)) * (2.0 ** -12 if flip else 1.0)).cuda()
+    r, db = T.conv9x9_c3_wgrad(act_b, img, ws, flip=flip, want_bias=True)
+    a64 = act_f.cpu().double().permute(0, 3, 1, 2)                          # (n, 96, hw, hw)
+    i64 = img.cpu().to(torch.bfloat16).double()
+    if flip:       # head: dw[co][ci][ky][kx] of conv2d(v, w, padding=4)[..., :125, :125]; r[ci][(co, ky, kx)]
+        dout = torch.zeros((n, 3, hw, hw), dtype=torch.float64)
+        dout[:, :, :ih, :ih] = i64
+        dw = torch.nn.grad.conv2d_weight(a64, (3, 96, 9, 9), dout, padding=4)
+        ref = dw.permute(1, 0, 2, 3).reshape(96, 243)
+    else:          # stem: dw[co][c3][ky][kx] of conv2d(lr, w, padding=4); r[co][(c3, ky, kx)]
+        ref = torch.nn.grad.conv2d_weight(i64, (96, 3, 9, 9), a64, padding=4).reshape(96, 243)
+    e = float((r.cpu().double() - ref).abs().max() / ref.abs().max())
+    eb = float((db.cpu().double() - a64.sum(dim=(0, 2, 3))).abs().max() / a64.sum(dim=(0, 2, 3)).abs().max())
+    print(f"  9x9 weight gradient (flip {flip}, n {n}) vs fp64 emulation: {e:.2e}, bias {eb:.2e}")
+    assert e <= 2e-5 and eb <= 2e-5, (e, eb)
 
 
 def test_pretrain_step_bf16_vs_reference_fp32_and_autocast_golden():
