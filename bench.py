@@ -274,7 +274,7 @@ def training_object(workload, precision, dev, rank, n_ranks, use_dist, n=64, ste
                                                                   f"{classes[top]['share']:.0%})",
                 "achieved": round(ach, 1) if ach else None, "peak": 8000.0, "unit": "GB/s",
                 "frac": round(ach / 8000.0, 4) if ach else None, "traffic": None, "ms_per_launch": round(top_ms / top_calls, 4)}
-    return {
+    out = {
         "metric": metric, "value": round(n * n_ranks * steps / dt, 1), "unit": "images/s", "n_gpus": n_ranks,
         "steps": steps, "warmup": max(warmup, 3), "ms_per_step": round(dt / steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -298,6 +298,13 @@ def training_object(workload, precision, dev, rank, n_ranks, use_dist, n=64, ste
                    "collective": "one all-reduce of the flat gradient buffer per optimizer step (12.86 MB generator, "
                                  "23.5 MB discriminator)"},
         "loss_last": float(loss), "roofline": roof, "time_by_operator_class": classes, "cpu_baseline": cpu}
+    if workload == "cfg4":
+        out["config"]["discriminator"] = (
+            "fp32 tensors; 64..512-channel convs on bf16 products with fp32 accumulation -- forward, data gradient and weight "
+            "gradient (LDS-tiled kernels srdisc_conv_bf16.hip / srdisc_wgrad_bf16.hip), what bf16 autocast gives them at "
+            "train.py:148-152,166-174; stem and tail on fp32 products" if b16 else
+            "fp32 tensors and products (v_mfma_f32_16x16x4_f32)")
+    return out
 
 
 def main():
