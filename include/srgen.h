@@ -341,7 +341,10 @@ SRGEN_API int srgen_adamw(float* p, const float* g, float* m, float* v, size_t n
  *   srgen_bn_train_fwd_bf16 / srgen_bn_train_bwd_bf16, srgen_prelu_scalar_fwd_bf16 / _bwd_bf16,
  *   srgen_chan_attn_nhwc_bf16 / srgen_chan_attn_bwd_bf16: as their fp32 namesakes
  *   srgen_conv9x9_c3_nhwc_split_bf16   fp32 3-channel image -> bf16 NHWC (stem forward, head data gradient)
- *   srgen_conv9x9_c3_wgrad_bf16        bf16 activation x fp32 image -> fp32 weight gradient
+ *   srgen_conv9x9_c3_wgrad_bf16        bf16 activation x fp32 image -> fp32 weight gradient.  Rows of 64 or 128 pixels (the
+ *                              generator's stem and head): v_mfma_f32_32x32x16_bf16, the image rounded to bf16 where it is
+ *                              multiplied (inside autocast the conv's image operand is bf16 too), fp32 accumulation; any
+ *                              other width: the fp32 matrix instruction on the operands as they are
  *   srgen_head_nhwc_bf16       bf16 (n,128,128,96) -> fp32 (n,3,125,125); wpack: bf16 8-element units [ky 9][g 6][h 2][n 32],
  *                              ci = 16 g + 8 h + e, n = 3 kx + co (27 of 32 used)
  */
