@@ -201,6 +201,44 @@ def test_discriminator_wgrad_bf16_products_vs_torch_emulation(cfg):
     assert 1e-6 <= d <= 3e-2, d
 
 
+def test_discriminator_bf16_products_full_batch_properties():
+    """BASELINE configs[4] sizes (64 images per GPU, 125 x 125): size-independent properties of the bf16-product kernels.
+    (1) Images are independent: logits and every saved activation of a 64-image forward equal, bit for bit, those of the
+        same images run as batches of 37, 26 and 1 (tiles never mix images in one accumulator, and the 8-wide layers pair
+        images without changing any image's summation order).
+    (2) The weight gradient is additive over the batch: the 64-image gradient equals the sum of the three sub-batch
+        gradients to fp32 summation order (2e-5 of max) -- slices that end inside an image, units that hang over it."""
+    from superresolution_amd import Discriminator, training as T
+    from superresolution_amd.gan_training import DiscriminatorGrad, disc_convs
+    torch.manual_seed(5)
+    d = Discriminator().cuda()
+    dg = DiscriminatorGrad(d, T.Workspace(torch.device("cuda", 0)))
+    dg.products = "bf16"
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand((64, 3, 125, 125), generator=g).cuda()
+    logits, saved = dg.forward(x)
+    dl = (torch.randn(logits.shape, generator=g) / logits.numel()).cuda()
+    parts = [(0, 37), (37, 63), (63, 64)]
+    for c in disc_convs(d):
+        c.weight.grad = None
+        c.bias.grad = None
+    grads = None
+    for a, b in parts:
+        lg, sv = dg.forward(x[a:b].contiguous())
+        assert torch.equal(lg, logits[a:b]), (a, b)
+        for i, (u, v) in enumerate(zip(sv["acts"], saved["acts"])):
+            assert torch.equal(u, v[a:b]), (a, b, i)
+        dg.backward(dl[a:b].contiguous(), sv, want_wgrad=True, want_dimg=False)          # accumulates into .grad
+    grads = [c.weight.grad.clone() for c in disc_convs(d)]
+    for c in disc_convs(d):
+        c.weight.grad = None
+        c.bias.grad = None
+    dg.backward(dl, saved, want_wgrad=True, want_dimg=False)
+    for i, (c, gsum) in enumerate(zip(disc_convs(d), grads)):
+        e = max_rel(c.weight.grad.cpu().numpy(), gsum.cpu().numpy())
+        assert e <= 2e-5, (i, e)
+
+
 def test_ragan_loss_grad_vs_torch_autograd():
     from superresolution_amd.gan_training import ragan_loss_grad
     g = torch.Generator().manual_seed(2)
