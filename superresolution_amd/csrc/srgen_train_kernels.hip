@@ -382,16 +382,19 @@ __global__ __launch_bounds__(1024) void conv3x3_wgrad_reduce_kernel(const float*
     const int idx = blockIdx.x * 64 + o;                     // over tap * 9216 + co * 96 + ci  (9 * 9216 = 1296 * 64)
     const int tap = idx / 9216, rem = idx % 9216;
     {
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        int sl = g;
-        for (; sl + 48 < slices; sl += 64) {
-            s0 += slab[((size_t)sl * 9 + tap) * 9216 + rem];
-            s1 += slab[((size_t)(sl + 16) * 9 + tap) * 9216 + rem];
-            s2 += slab[((size_t)(sl + 32) * 9 + tap) * 9216 + rem];
-            s3 += slab[((size_t)(sl + 48) * 9 + tap) * 9216 + rem];
+        // up to 16 partials per thread (slices <= 256), ALL requested before the first is added: the loop of four loads in
+        // flight walked 168 slices in five dependent L2 round trips (17 us per gradient for 56 MB that sit in the cache)
+        float v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int sl = g + 16 * k;
+            v[k] = sl < slices ? slab[((size_t)sl * 9 + tap) * 9216 + rem] : 0.f;
         }
-        for (; sl < slices; sl += 16) s0 += slab[((size_t)sl * 9 + tap) * 9216 + rem];
-        part[g][o] = (s0 + s1) + (s2 + s3);
+        float s = 0.f;
+        for (int sl = g + 256; sl < slices; sl += 16) s += slab[((size_t)sl * 9 + tap) * 9216 + rem];      // (never with today's slice counts)
+#pragma unroll
+        for (int k = 0; k < 16; k += 4) s += (v[k] + v[k + 1]) + (v[k + 2] + v[k + 3]);
+        part[g][o] = s;
     }
     __syncthreads();
     if (g == 0) {
