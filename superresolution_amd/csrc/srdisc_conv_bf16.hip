@@ -70,9 +70,20 @@ __device__ __forceinline__ void glds16_raw(const void* sbase, unsigned voff, uns
                  :: "v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
 }
 
+// One launch runs up to four convs over the same input with different tap lists, weight packs and output pixel sets:
+// the four output-parity classes of a stride-2 data gradient (1, 2, 2 and 4 taps: separate launches left the 16 x 16 and
+// 8 x 8 layers with a quarter of the chip each); a plain conv is one class.
+struct ConvClass {
+    int OH, OW, tiles_x, tiles_y;      // the grid this class runs over and its tiling
+    int NT, py, px;                    // taps; output pixel (oy, ox) of the class is pixel (2 oy + py, 2 ox + px) (parity classes)
+    int wg_end;                        // workgroups [wg_end of the class before, wg_end) are this class's
+    unsigned long long taps;           // 4-bit tap ids (ky * 3 + kx)
+    long long wbytes;                  // byte offset of the class's weight pack behind a.wpack
+};
+struct ConvClasses { ConvClass c[4]; };
+
 template <int S, bool NARROW, int BN>
-__global__ __launch_bounds__(256, 2) void disc_conv_lds_kernel(DiscConvArgs a, int OH, int OW, int tiles_x, int tiles_y,
-                                                               int total_wgs, int NT, unsigned long long taps)
+__global__ __launch_bounds__(256, 2) void disc_conv_lds_kernel(DiscConvArgs a, ConvClasses cls, int total_wgs)
 {
     using G = Geo<S, NARROW>;
     constexpr int TW = G::TW, TH = G::TH, TI = G::TI, HR = G::HR, HC = G::HC, NPX = G::NPX, NA = G::NA, CE = G::CE;
@@ -87,8 +98,21 @@ __global__ __launch_bounds__(256, 2) void disc_conv_lds_kernel(DiscConvArgs a, i
     // workgroup ids b, b + 8, ... share an XCD (private L2): XCD x takes a contiguous run of (tile, channel block) pairs,
     // the channel blocks of one tile next to each other, so a halo tile is fetched into one L2
     const int per_xcd = (total_wgs + 7) >> 3;
-    const int lid = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+    int lid = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
     if (lid >= total_wgs) return;
+    ConvClass k = cls.c[0];
+#pragma unroll
+    for (int j = 1; j < 4; ++j)
+        if (lid >= cls.c[j - 1].wg_end) k = cls.c[j];              // (wave-uniform; unused classes have wg_end = total_wgs)
+    {
+        int first = 0;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (lid >= cls.c[j].wg_end) first = cls.c[j].wg_end;
+        lid -= first;
+    }
+    const int OH = k.OH, OW = k.OW, tiles_x = k.tiles_x, tiles_y = k.tiles_y, NT = k.NT;
+    const unsigned long long taps = k.taps;
     const int ncb = a.Cout / BN;
     const int cb = lid % ncb;
     int tile = lid / ncb;
@@ -135,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void disc_conv_lds_kernel(DiscConvArgs a, i
 
     // ---- weight slabs: [cb][chunk][tap] x SLAB bytes, wave w copies pieces w, w + 4 ----
     const int nchunks = a.Cin >> 5, nslabs = nchunks * NT;
-    const char* const wsrc = (const char*)a.wpack + (size_t)cb * nslabs * SLAB;
+    const char* const wsrc = (const char*)a.wpack + k.wbytes + (size_t)cb * nslabs * SLAB;
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
     const unsigned lane16 = (unsigned)lane * 16u;
     auto issue_slab = [&](int j, int slot) {
@@ -158,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void disc_conv_lds_kernel(DiscConvArgs a, i
         abase[mt] = ((ti * HR + r * S) * HC + c) * PITCH + h * 16;
         const int img = img0 + ti, oy = oy0 + r, ox = ox0 + c;
         const bool valid = img < a.N && oy < OH && ox < OW;
-        const int pix = par ? (img * a.FH + 2 * oy + a.py) * a.FW + 2 * ox + a.px : (img * OH + oy) * OW + ox;
+        const int pix = par ? (img * a.FH + 2 * oy + k.py) * a.FW + 2 * ox + k.px : (img * OH + oy) * OW + ox;
         ooff[mt] = valid ? pix * a.Cout + cb * BN + wn * (BN / 2) + 4 * h : -1;
     }
 
@@ -254,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void disc_conv_lds_kernel(DiscConvArgs a, i
 }
 
 template <int S, bool NARROW, int BN>
-static hipError_t launch_one(const DiscConvArgs& a, int OH, int OW, int NT, unsigned long long taps, hipStream_t s)
+static hipError_t launch_one(const DiscConvArgs& a, ConvClasses cls, int nclasses, hipStream_t s)
 {
     using G = Geo<S, NARROW>;
     constexpr int lds_bytes = G::A_BYTES + NRING * BN * 64;
@@ -268,37 +292,28 @@ static hipError_t launch_one(const DiscConvArgs& a, int OH, int OW, int NT, unsi
         if (e != hipSuccess) return e;
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    const int tiles_x = (OW + G::TW - 1) / G::TW, tiles_y = (OH + G::TH - 1) / G::TH, groups = (a.N + G::TI - 1) / G::TI;
-    const long long total = (long long)groups * tiles_y * tiles_x * (a.Cout / BN);
-    if (total <= 0 || total > 0x3fffffffLL) return hipErrorInvalidValue;
+    const int groups = (a.N + G::TI - 1) / G::TI;
+    long long total = 0;
+    for (int j = 0; j < 4; ++j) {
+        ConvClass& c = cls.c[j];
+        if (j < nclasses) {
+            c.tiles_x = (c.OW + G::TW - 1) / G::TW;
+            c.tiles_y = (c.OH + G::TH - 1) / G::TH;
+            total += (long long)groups * c.tiles_y * c.tiles_x * (a.Cout / BN);
+        }
+        if (total > 0x3fffffffLL) return hipErrorInvalidValue;
+        c.wg_end = (int)total;                       // (an unused class: an empty range at the end)
+    }
+    if (total <= 0) return hipSuccess;
     const unsigned grid = (unsigned)((total + 7) / 8 * 8);
-    hipLaunchKernelGGL((disc_conv_lds_kernel<S, NARROW, BN>), dim3(grid), dim3(256), lds_bytes, s, a, OH, OW, tiles_x, tiles_y,
-                       (int)total, NT, taps);
+    hipLaunchKernelGGL((disc_conv_lds_kernel<S, NARROW, BN>), dim3(grid), dim3(256), lds_bytes, s, a, cls, (int)total);
     return hipGetLastError();
 }
 
-}  // namespace dcl
-
-// a.bf16 convs of launch_disc_conv / launch_disc_dgrad2 (srdisc_kernels.hip): OH x OW = the grid the conv runs over (the
-// layer's output, or one parity class of a stride-2 layer's input when par), wpack = launch_disc_pack(.., bf16 = true)
-hipError_t launch_disc_conv_bf16(const DiscConvArgs& a, int OH, int OW, bool par, hipStream_t s)
+static hipError_t dispatch(const DiscConvArgs& a, const ConvClasses& cls, int nclasses, int stride, bool narrow, hipStream_t s)
 {
-    using namespace dcl;
-    if (a.Cin % 32 || a.Cout % 64 || OH < 1 || OW < 1 || a.N < 1) return hipErrorInvalidValue;
-    if ((long long)a.N * a.H * a.W * a.Cin > 0x3fffffffLL) return hipErrorInvalidValue;      // 32-bit byte offsets
-    const long long out_px = par ? (long long)a.N * a.FH * a.FW : (long long)a.N * OH * OW;
-    if (out_px * a.Cout > 0x7fffffffLL) return hipErrorInvalidValue;
-    int NT = 9;
-    unsigned long long taps = 0x876543210ull;
-    int stride = a.stride;
-    if (par) {
-        if (a.nreal < 1 || a.nreal > 4 || a.FH < 1 || a.FW < 1) return hipErrorInvalidValue;
-        NT = a.nreal;
-        taps = a.taps;
-        stride = 1;
-    }
-    const bool narrow = OW <= 8, wide_n = a.Cout % 128 == 0;
-#define DCL_GO(S_, NAR_, BN_) return launch_one<S_, NAR_, BN_>(a, OH, OW, NT, taps, s)
+    const bool wide_n = a.Cout % 128 == 0;
+#define DCL_GO(S_, NAR_, BN_) return launch_one<S_, NAR_, BN_>(a, cls, nclasses, s)
     if (stride == 1) {
         if (narrow) { if (wide_n) DCL_GO(1, true, 128); else DCL_GO(1, true, 64); }
         if (wide_n) DCL_GO(1, false, 128); else DCL_GO(1, false, 64);
@@ -309,6 +324,68 @@ hipError_t launch_disc_conv_bf16(const DiscConvArgs& a, int OH, int OW, bool par
     }
 #undef DCL_GO
     return hipErrorInvalidValue;
+}
+
+static bool sizes_ok(const DiscConvArgs& a, long long out_px)
+{
+    if (a.Cin % 32 || a.Cout % 64 || a.N < 1 || a.H < 1 || a.W < 1) return false;
+    if ((long long)a.N * a.H * a.W * a.Cin > 0x3fffffffLL) return false;       // 32-bit byte offsets
+    return out_px * a.Cout <= 0x7fffffffLL;
+}
+
+}  // namespace dcl
+
+// the a.bf16 convs of launch_disc_conv (srdisc_kernels.hip): wpack = launch_disc_pack(.., mode 0 | 1, bf16 = true)
+hipError_t launch_disc_conv_bf16(const DiscConvArgs& a, int OH, int OW, hipStream_t s)
+{
+    using namespace dcl;
+    if (OH < 1 || OW < 1 || !sizes_ok(a, (long long)a.N * OH * OW) || (a.stride != 1 && a.stride != 2)) return hipErrorInvalidValue;
+    DiscConvArgs b = a;
+    b.FH = b.FW = 0;                                 // (not a parity class)
+    ConvClasses cls = {};
+    cls.c[0].OH = OH;
+    cls.c[0].OW = OW;
+    cls.c[0].NT = 9;
+    cls.c[0].taps = 0x876543210ull;
+    return dispatch(b, cls, 1, a.stride, OW <= 8, s);
+}
+
+// the a0.bf16 data gradient of a stride-2 layer (launch_disc_dgrad2): the four output-parity classes of the fh x fw input
+// grid in ONE launch; a0.H x a0.W = the layer's output grid (dpre), wpack4 = the four class packs back to back
+// (launch_disc_pack mode 4, bf16: 1, 2, 2 and 4 taps)
+hipError_t launch_disc_dgrad2_bf16(const DiscConvArgs& a0, const void* wpack4, int fh, int fw, hipStream_t s)
+{
+    using namespace dcl;
+    if (fh < 1 || fw < 1 || !a0.mask || !sizes_ok(a0, (long long)a0.N * fh * fw)) return hipErrorInvalidValue;
+    DiscConvArgs a = a0;
+    a.stride = 1;
+    a.wpack = (const float*)wpack4;
+    a.FH = fh;
+    a.FW = fw;
+    ConvClasses cls = {};
+    long long woff = 0;
+    int n = 0, max_cw = 0;
+    for (int c = 0; c < 4; ++c) {
+        const int py = c >> 1, px = c & 1;
+        const int ntaps = (py + 1) * (px + 1);
+        const int CH = (fh - py + 1) / 2, CW = (fw - px + 1) / 2;          // rows / columns of that parity in the image
+        if (CH > 0 && CW > 0) {
+            ConvClass& k = cls.c[n++];
+            k.OH = CH;
+            k.OW = CW;
+            k.NT = ntaps;
+            k.py = py;
+            k.px = px;
+            k.wbytes = woff * 2;                     // bf16
+            int t = 0;
+            for (int ky = 1; ky <= 1 + py; ++ky)
+                for (int kx = 1; kx <= 1 + px; ++kx) k.taps |= (unsigned long long)(ky * 3 + kx) << (4 * t++);
+            if (CW > max_cw) max_cw = CW;
+        }
+        woff += (long long)ntaps * a0.Cin * a0.Cout;
+    }
+    if (n == 0) return hipSuccess;
+    return dispatch(a, cls, n, 1, max_cw <= 8, s);
 }
 
 }  // namespace srgen

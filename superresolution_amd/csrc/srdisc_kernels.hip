@@ -414,7 +414,7 @@ hipError_t launch_disc_stem(const DiscStemArgs& a, hipStream_t s)
 
 static hipError_t launch_conv_grid(const DiscConvArgs& a, int OH, int OW, long long M, bool par, hipStream_t s)
 {
-    if (a.bf16) return launch_disc_conv_bf16(a, OH, OW, par, s);       // bf16 products: the LDS-tiled kernel (srdisc_conv_bf16.hip)
+    if (a.bf16) return par ? hipErrorInvalidValue : launch_disc_conv_bf16(a, OH, OW, s);      // bf16 products: the LDS-tiled kernel
     const int nst = a.Cin >> 6;                 // steps of 64 input channels per tap
     int lg = 0;
     while ((1 << lg) < nst) ++lg;
@@ -470,6 +470,7 @@ hipError_t launch_disc_dgrad2(const DiscConvArgs& a0, const float* wpack4, int f
 {
     if (a0.N <= 0) return hipSuccess;
     if (!conv_args_ok(a0) || !a0.mask || (fh - 1) / 2 + 1 != a0.H || (fw - 1) / 2 + 1 != a0.W) return hipErrorInvalidValue;
+    if (a0.bf16) return launch_disc_dgrad2_bf16(a0, wpack4, fh, fw, s);        // one launch for the four classes (srdisc_conv_bf16.hip)
     const int nst = a0.Cin >> 6;
     size_t woff = 0;
     for (int c = 0; c < 4; ++c) {

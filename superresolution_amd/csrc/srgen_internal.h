@@ -277,8 +277,9 @@ struct DiscTailArgs {          // conv Cin -> 1, stride 1, pad 1, no activation
 hipError_t launch_disc_stem(const DiscStemArgs& a, hipStream_t s);
 hipError_t launch_disc_conv(const DiscConvArgs& a, hipStream_t s);
 hipError_t launch_disc_dgrad2(const DiscConvArgs& a0, const float* wpack4, int fh, int fw, hipStream_t s);
-// the a.bf16 convs (srdisc_conv_bf16.hip): OH x OW = the grid the conv runs over, par: one parity class of a stride-2 data gradient
-hipError_t launch_disc_conv_bf16(const DiscConvArgs& a, int OH, int OW, bool par, hipStream_t s);
+// the a.bf16 convs (srdisc_conv_bf16.hip): OH x OW = the layer's output grid; the stride-2 data gradient's four parity classes in one launch
+hipError_t launch_disc_conv_bf16(const DiscConvArgs& a, int OH, int OW, hipStream_t s);
+hipError_t launch_disc_dgrad2_bf16(const DiscConvArgs& a0, const void* wpack4, int fh, int fw, hipStream_t s);
 hipError_t launch_disc_tail(const DiscTailArgs& a, hipStream_t s);
 hipError_t launch_ragan_loss(const float* real, const float* fake, size_t n_real, size_t n_fake,
                              float real_label, float fake_label, float* out2, hipStream_t s);
