@@ -99,3 +99,14 @@ def test_discriminator_argument_errors_without_gpu():
     assert L.srdisc_set_tensor(None, b"backbone.0.weight", None, 0) == -1
     assert L.srdisc_forward(None, None, None, None, 0, 1, 125, 125, None, None) == -1
     assert L.srgen_ragan_loss(None, None, 1, 1, 0.9, 0.1, None, None) == -1
+    # the bf16-product operators of the GAN step: argument checks come before any HIP call
+    assert L.srdisc_pack_bf16(None, 64, 64, 0, None, None) == -1
+    assert L.srdisc_conv_nhwc_bf16p(None, None, None, None, None, 1, 16, 16, 64, 64, 1, 0.2, None) == -1
+    assert L.srdisc_conv_dgrad2_bf16p(None, None, None, None, 1, 16, 16, 64, 64, 0.2, None) == -1
+    assert L.srdisc_conv_wgrad_bf16p(None, None, 1, 16, 16, 64, 64, 1, None, None, None, 0, None) == -1
+    assert b"NULL" in L.srgen_last_error()
+    need = ctypes.c_size_t()
+    assert L.srdisc_conv_wgrad_scratch_bytes(2, 16, 64, 128, 1, ctypes.byref(need)) == 0
+    # (one scratch size serves the fp32-product and the bf16-product gradient: at least the bf16 kernel's slab of
+    # ceil(256 / tiles) slices x 9 x cin x cout floats + the bias partials)
+    assert need.value >= (128 * 9 * 64 * 128 + 128 * 128) * 4
