@@ -95,7 +95,8 @@ class DiscriminatorGrad:
         """Kernel-side image of a conv's live weights (made on the device).  Kept until the parameter changes: the
         discriminator is updated every third iteration only (config.py:21), and a generator half-step packs the same
         weights its discriminator half-step just used.  A change is an in-place update (the version counter every torch
-        optimizer and FlatAdamW bump) or a new storage."""
+        optimizer and FlatAdamW bump) or a new storage.  Writes that bypass the version counter (``p.data.copy_(...)``,
+        raw kernels) need ``invalidate_packs()``."""
         p = conv.weight
         bf16 = bf16 and mode in (0, 1, 4)
         key, tag = (id(conv), mode, bf16), (p._version, p.data_ptr())
@@ -111,6 +112,10 @@ class DiscriminatorGrad:
             _lib.check(fn(w.data_ptr(), cin, cout, mode, out.data_ptr(), _stream(w)))
         self._packs[key] = (tag, out)
         return out
+
+    def invalidate_packs(self) -> None:
+        """Forget every kept weight image (after a weight write torch's version counters do not see)."""
+        self._packs.clear()
 
     # -- forward --------------------------------------------------------------------------------------------------------
     @_timed("discriminator forward")
