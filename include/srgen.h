@@ -269,6 +269,14 @@ SRGEN_API int srgen_prelu_scratch_bytes(size_t* bytes);
 SRGEN_API int srgen_prelu_scalar_fwd(const float* x, const float* slope, float* y, size_t numel, void* stream);
 SRGEN_API int srgen_prelu_scalar_bwd(const float* x, const float* dy, const float* dy2, const float* slope, float* dx,
                                      float* dslope, size_t numel, void* scratch, size_t scratch_bytes, void* stream);
+/* Replaces: the same backward for the upsample block (Generator.py:8-9: PixelShuffle, then PReLU) together with the
+ * PixelShuffle's backward: x, dy (n, full, full, 96) NHWC; dx (2, 2, n, full/2, full/2, 96): plane (i, j) holds the gradient
+ * at pixels (2y + i, 2x + j), i.e. of conv-output block 2i + j -- what the four data- / weight-gradient convs of the
+ * 96 -> 384 conv read, without a permute copy.  _bf16: bf16 x, dy, dx (the 16-bit step). */
+SRGEN_API int srgen_prelu_scalar_bwd_unshuffle(const float* x, const float* dy, const float* slope, float* dx, float* dslope,
+                                               int n, int full, void* scratch, size_t scratch_bytes, void* stream);
+SRGEN_API int srgen_prelu_scalar_bwd_unshuffle_bf16(const void* x, const void* dy, const float* slope, void* dx, float* dslope,
+                                                    int n, int full, void* scratch, size_t scratch_bytes, void* stream);
 
 /* Replaces: the 9x9 convs between a 3-channel NCHW image and a 96-channel NHWC tensor, in the four forms the step needs
  * (Generator.py:50 input[0], :71 output[2]).  j = (c3, ky, kx) runs over 243 taps; a tap of pixel (y, x) reads

@@ -102,6 +102,10 @@ def lib() -> ctypes.CDLL:
     L.srgen_prelu_scratch_bytes.argtypes = [ctypes.POINTER(sz)]
     L.srgen_prelu_scalar_fwd.argtypes = [vp, vp, vp, sz, vp]
     L.srgen_prelu_scalar_bwd.argtypes = [vp, vp, vp, vp, vp, vp, sz, vp, sz, vp]
+    L.srgen_prelu_scalar_bwd_unshuffle.argtypes = [vp, vp, vp, vp, vp, i, i, vp, sz, vp]
+    L.srgen_prelu_scalar_bwd_unshuffle.restype = i
+    L.srgen_prelu_scalar_bwd_unshuffle_bf16.argtypes = L.srgen_prelu_scalar_bwd_unshuffle.argtypes
+    L.srgen_prelu_scalar_bwd_unshuffle_bf16.restype = i
     L.srgen_conv9x9_c3_nhwc.argtypes = [vp, vp, vp, vp, i, i, i, i, i, i, vp]
     L.srgen_conv9x9_c3_nhwc_split.argtypes = [vp, vp, vp, vp, i, i, i, i, i, i, vp, sz, vp]
     L.srgen_conv9x9_c3_wgrad_scratch_bytes.argtypes = [i, i, ctypes.POINTER(sz)]

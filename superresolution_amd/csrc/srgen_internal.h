@@ -382,6 +382,8 @@ hipError_t launch_bn_train_bwd_bf16(const void* c, const void* dt, const float* 
 hipError_t launch_prelu_scalar_fwd_bf16(const void* x, const float* slope, void* y, size_t numel, hipStream_t s);
 hipError_t launch_prelu_scalar_bwd_bf16(const void* x, const void* dy, const void* dy2, const float* slope, void* dx,
                                         float* dslope, size_t numel, void* scratch, hipStream_t s);
+hipError_t launch_prelu_scalar_bwd_unshuffle(const void* x, const void* dy, const float* slope, void* dx, float* dslope, int n, int full,
+                                             void* scratch, hipStream_t s, bool bf16);
 hipError_t launch_conv9x9_c3_wgrad_bf16(const void* act, const float* img, int n, int ah, int aw, int ih, int iw, int flip, float* r,
                                         float* dbias, void* scratch, hipStream_t s);
 hipError_t launch_conv9x9_c3_wgrad_reduce(const float* slab, const float* bias_slab, int slices, float* r, float* dbias, hipStream_t s);

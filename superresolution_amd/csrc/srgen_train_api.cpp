@@ -288,6 +288,29 @@ int srgen_prelu_scalar_bwd(const float* x, const float* dy, const float* dy2, co
     return SRGEN_OK;
 }
 
+static int prelu_bwd_unshuffle_any(const void* x, const void* dy, const float* slope, void* dx, float* dslope, int n, int full,
+                                   void* scratch, size_t scratch_bytes, void* stream, bool bf16)
+{
+    if (!x || !dy || !slope || !dx || !dslope || !scratch) return fail(SRGEN_E_INVALID, "NULL argument");
+    if (n <= 0 || full <= 0 || (full & 1)) return fail(SRGEN_E_INVALID, "n %d, full size %d (even)", n, full);
+    if (!aligned16(x) || !aligned16(dy) || !aligned16(dx)) return fail(SRGEN_E_INVALID, "operands must be 16-byte aligned");
+    if (scratch_bytes < prelu_scratch_bytes()) return fail(SRGEN_E_WORKSPACE, "PReLU scratch too small");
+    HIP_TRY(launch_prelu_scalar_bwd_unshuffle(x, dy, slope, dx, dslope, n, full, scratch, (hipStream_t)stream, bf16));
+    return SRGEN_OK;
+}
+
+int srgen_prelu_scalar_bwd_unshuffle(const float* x, const float* dy, const float* slope, float* dx, float* dslope, int n, int full,
+                                     void* scratch, size_t scratch_bytes, void* stream)
+{
+    return prelu_bwd_unshuffle_any(x, dy, slope, dx, dslope, n, full, scratch, scratch_bytes, stream, false);
+}
+
+int srgen_prelu_scalar_bwd_unshuffle_bf16(const void* x, const void* dy, const float* slope, void* dx, float* dslope, int n, int full,
+                                          void* scratch, size_t scratch_bytes, void* stream)
+{
+    return prelu_bwd_unshuffle_any(x, dy, slope, dx, dslope, n, full, scratch, scratch_bytes, stream, true);
+}
+
 int srgen_conv9x9_c3_nhwc(const float* img, const float* wm, const float* bias, float* out, int n, int ih, int iw, int oh, int ow,
                           int flip, void* stream)
 {

@@ -1206,10 +1206,15 @@ __global__ __launch_bounds__(256) void prelu_scalar_fwd_kernel(const T* __restri
 
 // dx = dy * (x >= 0 ? 1 : a), dy = dy1 (+ dy2: a second consumer of the PReLU output, e.g. the long skip);
 // per-workgroup partial of da = sum dy * x * [x < 0] (fp64 across threads)
-template <typename T>
+// UNSH (the upsample block's PReLU, Generator.py:8-9 backward): dx is written in the layout the PixelShuffle's backward
+// wants -- (2, 2, n, full/2, full/2, 96): plane (y & 1, x & 1) holds the gradient of conv-output block 2 (y & 1) + (x & 1) --
+// so the four data-gradient / weight-gradient convs below read contiguous tensors and no permute copy runs (129 us per
+// 64-image step for a pass this kernel makes anyway).
+template <typename T, bool UNSH = false>
 __global__ __launch_bounds__(256) void prelu_scalar_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                                const T* __restrict__ dy2, const float* __restrict__ slope,
-                                                               T* __restrict__ dx, size_t nvec, double* __restrict__ partial)
+                                                               T* __restrict__ dx, size_t nvec, double* __restrict__ partial,
+                                                               unsigned nimg = 0, unsigned full = 0)
 {
     constexpr int V = StoreVec<T>::N;
     __shared__ double red[256];
@@ -1228,7 +1233,16 @@ __global__ __launch_bounds__(256) void prelu_scalar_bwd_kernel(const T* __restri
 #pragma unroll
         for (int e = 0; e < V; ++e)
             if (v[e] < 0.f) { acc += d[e] * v[e]; d[e] *= a; }
-        stv(dx + i * V, d);
+        size_t j = i;
+        if (UNSH) {
+            constexpr unsigned CPP = 96 / V;
+            const size_t pixel = i / CPP;
+            const unsigned c = (unsigned)(i - pixel * CPP);
+            const unsigned xx = (unsigned)(pixel % full), t = (unsigned)(pixel / full);
+            const unsigned yy = t % full, n = t / full, half = full >> 1;
+            j = ((((size_t)((yy & 1u) * 2u + (xx & 1u)) * nimg + n) * half + (yy >> 1)) * half + (xx >> 1)) * CPP + c;
+        }
+        stv(dx + j * V, d);
     }
     red[threadIdx.x] = (double)acc;
     __syncthreads();
@@ -1268,12 +1282,17 @@ static hipError_t prelu_fwd_t(const T* x, const float* slope, T* y, size_t numel
 
 template <typename T>
 static hipError_t prelu_bwd_t(const T* x, const T* dy, const T* dy2, const float* slope, T* dx, float* dslope, size_t numel,
-                              void* scratch, hipStream_t s)
+                              void* scratch, hipStream_t s, int unshuffle_n = 0, int full = 0)
 {
     const size_t n4 = numel / StoreVec<T>::N;
     size_t nb = (n4 + 255) / 256;
     if (nb > PRELU_BLOCKS) nb = PRELU_BLOCKS;
-    hipLaunchKernelGGL(prelu_scalar_bwd_kernel<T>, dim3((unsigned)nb), dim3(256), 0, s, x, dy, dy2, slope, dx, n4, (double*)scratch);
+    if (unshuffle_n > 0)
+        hipLaunchKernelGGL((prelu_scalar_bwd_kernel<T, true>), dim3((unsigned)nb), dim3(256), 0, s, x, dy, dy2, slope, dx, n4,
+                           (double*)scratch, (unsigned)unshuffle_n, (unsigned)full);
+    else
+        hipLaunchKernelGGL((prelu_scalar_bwd_kernel<T, false>), dim3((unsigned)nb), dim3(256), 0, s, x, dy, dy2, slope, dx, n4,
+                           (double*)scratch, 0u, 0u);
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, (const double*)scratch, (int)nb, dslope);
     return hipGetLastError();
 }
@@ -1287,6 +1306,16 @@ hipError_t launch_prelu_scalar_bwd(const float* x, const float* dy, const float*
                                    size_t numel, void* scratch, hipStream_t s)
 {
     return prelu_bwd_t<float>(x, dy, dy2, slope, dx, dslope, numel, scratch, s);
+}
+
+// x, dy (n, full, full, 96) -> dx (2, 2, n, full/2, full/2, 96)
+hipError_t launch_prelu_scalar_bwd_unshuffle(const void* x, const void* dy, const float* slope, void* dx, float* dslope, int n, int full,
+                                             void* scratch, hipStream_t s, bool bf16)
+{
+    const size_t numel = (size_t)n * full * full * 96;
+    if (bf16)
+        return prelu_bwd_t<bf16_t>((const bf16_t*)x, (const bf16_t*)dy, nullptr, slope, (bf16_t*)dx, dslope, numel, scratch, s, n, full);
+    return prelu_bwd_t<float>((const float*)x, (const float*)dy, nullptr, slope, (float*)dx, dslope, numel, scratch, s, n, full);
 }
 
 hipError_t launch_prelu_scalar_fwd_bf16(const void* x, const float* slope, void* y, size_t numel, hipStream_t s)

@@ -672,16 +672,29 @@ def prelu_scalar(x: torch.Tensor, slope: torch.Tensor) -> torch.Tensor:
 
 
 @_timed("scalar PReLU", _bytes_of(3))
-def prelu_scalar_bwd(x, dy, slope, ws: Workspace, dy2=None):
-    """(dx, dslope (1,)) given the pre-activation ``x`` and ``dy`` (+ ``dy2``, a second consumer's gradient)."""
+def prelu_scalar_bwd(x, dy, slope, ws: Workspace, dy2=None, unshuffle: bool = False):
+    """(dx, dslope (1,)) given the pre-activation ``x`` and ``dy`` (+ ``dy2``, a second consumer's gradient).
+    ``unshuffle`` (the upsample block: PixelShuffle, then PReLU): ``dx`` comes back as (2, 2, n, h/2, w/2, 96) with
+    ``dx[i, j, n, y, x] =`` the gradient at pixel (2y + i, 2x + j) -- the PixelShuffle's backward folded into the store."""
     need = ctypes.c_size_t()
     _lib.check(_lib.lib().srgen_prelu_scratch_bytes(ctypes.byref(need)))
     scratch = ws.get("prelu", need.value)
-    dx = torch.empty_like(x)
     dslope = torch.empty(1, dtype=torch.float32, device=x.device)
     if dy.dtype != x.dtype or (dy2 is not None and dy2.dtype != x.dtype):
         raise RuntimeError("prelu_scalar_bwd: operands of one storage type")
-    op = _lib.lib().srgen_prelu_scalar_bwd_bf16 if _bf(x) else _lib.lib().srgen_prelu_scalar_bwd
+    L = _lib.lib()
+    if unshuffle:
+        n, h, w, c = x.shape
+        if dy2 is not None or h != w or (h & 1) or c != 96 or not x.is_contiguous() or not dy.is_contiguous():
+            raise RuntimeError("prelu_scalar_bwd(unshuffle=True): contiguous (n, 2k, 2k, 96) operands, no second gradient")
+        dx = torch.empty((2, 2, n, h // 2, w // 2, 96), dtype=x.dtype, device=x.device)
+        op = L.srgen_prelu_scalar_bwd_unshuffle_bf16 if _bf(x) else L.srgen_prelu_scalar_bwd_unshuffle
+        with torch.cuda.device(x.device):
+            _lib.check(op(x.data_ptr(), dy.data_ptr(), slope.data_ptr(), dx.data_ptr(), dslope.data_ptr(), n, h,
+                          scratch.data_ptr(), scratch.numel(), _stream(x)))
+        return dx, dslope
+    dx = torch.empty_like(x)
+    op = L.srgen_prelu_scalar_bwd_bf16 if _bf(x) else L.srgen_prelu_scalar_bwd
     with torch.cuda.device(x.device):
         _lib.check(op(x.data_ptr(), dy.data_ptr(), dy2.data_ptr() if dy2 is not None else None,
                                                      slope.data_ptr(), dx.data_ptr(), dslope.data_ptr(), x.numel(),
@@ -954,10 +967,8 @@ class GeneratorGrad:
         du = conv3x3(dv_pre, conv_pack(g.output[0].weight, mode=1), scale_input=True)
         # upsample: conv 96 -> 384, PixelShuffle(2), scalar PReLU (Generator.py:4-12)
         up = g.upsample
-        du_pre, ds = prelu_scalar_bwd(S["u_pre"], du, up.act.weight.detach(), ws)
+        planes, ds = prelu_scalar_bwd(S["u_pre"], du, up.act.weight.detach(), ws, unshuffle=True)     # [i][j] -> (n, 64, 64, 96)
         put("upsample.act.weight", ds)
-        n = du_pre.shape[0]
-        planes = du_pre.view(n, 64, 2, 64, 2, 96).permute(2, 4, 0, 1, 3, 5).contiguous()     # [i][j] -> (n, 64, 64, 96)
         gw, gb = G["upsample.conv.weight"].view(96, 4, 96, 3, 3), G["upsample.conv.bias"].view(96, 4)
         dm = None
         for b in range(4):

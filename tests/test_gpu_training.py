@@ -392,6 +392,24 @@ def _ref_grad_norm(model):                                        # train.py:23-
     return total ** 0.5
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_prelu_backward_with_the_pixel_shuffle_backward_folded_into_its_store(dtype):
+    """prelu_scalar_bwd(unshuffle=True) (the upsample block, Generator.py:8-9): the same numbers as the plain operator,
+    stored as the (2, 2, n, h/2, w/2, 96) planes the PixelShuffle's backward makes -- bit for bit what the permute copy
+    made from the plain result; dslope identical."""
+    from superresolution_amd import training as T
+    ws = T.Workspace(torch.device("cuda"))
+    x = _nhwc(_hash_tensor(61, "px", (3, 96, 128, 128), -1.0, 1.0)).to(dtype).cuda().contiguous()
+    dy = (_nhwc(_hash_tensor(62, "pd", (3, 96, 128, 128), -1.0, 1.0)) * 2.0 ** -10).to(dtype).cuda().contiguous()
+    slope = torch.tensor([0.25], device="cuda")
+    dx, ds = T.prelu_scalar_bwd(x, dy, slope, ws)
+    planes, ds2 = T.prelu_scalar_bwd(x, dy, slope, ws, unshuffle=True)
+    ref = dx.view(3, 64, 2, 64, 2, 96).permute(2, 4, 0, 1, 3, 5).contiguous()
+    assert planes.shape == (2, 2, 3, 64, 64, 96) and planes.dtype == dtype
+    assert torch.equal(planes, ref)
+    assert torch.equal(ds, ds2)
+
+
 def test_reference_pretrain_loop_body_runs_on_the_dropin_generator():
     """train.py:90-97 verbatim -- ``optimizer.zero_grad(); sr = generator(lr); loss = weighted_l1(sr, hr) + 0.1 * (1 -
     ssim(sr, hr)); loss.backward(); grad_norm(generator); optimizer.step()`` -- with a STOCK ``torch.optim.AdamW`` on
