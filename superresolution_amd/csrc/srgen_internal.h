@@ -223,6 +223,7 @@ hipError_t launch_stem_bf16(const StemArgs& a, hipStream_t s);
 hipError_t launch_conv3x3_bf16(const Conv3x3Args& a, hipStream_t s);
 hipError_t launch_chan_attn_bf16(const ChanAttnArgs& a, hipStream_t s);
 hipError_t launch_head_bf16(const HeadArgs& a, hipStream_t s);
+hipError_t launch_head_bf16_stream(const HeadArgs& a, hipStream_t s);      // srgen_head_bf16_stream.hip
 
 // misc (srgen_kernels_misc.hip)
 hipError_t launch_nhwc_to_nchw_f32(const void* in, int in_is_bf16, float* out, int N, int HW,

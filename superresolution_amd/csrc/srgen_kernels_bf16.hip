@@ -11,6 +11,8 @@
 // and B[k 8h+j][col r], j = 0..7; accumulator register q of lane l is
 // C[row (q&3) + 8*(q>>2) + 4h][col r].
 #include "srgen_internal.h"
+#include <cstdlib>
+#include <cstring>
 
 namespace srgen {
 
@@ -353,6 +355,10 @@ __global__ __launch_bounds__(256, 2) void head_bf16_kernel(HeadArgs a)
 
 hipError_t launch_head_bf16(const HeadArgs& a, hipStream_t s)
 {
+    {
+        const char* e = getenv("SRGEN_HEAD_BF16");            // development switch, read per call: "tile" = this file's kernel
+        if (!(e && !strcmp(e, "tile"))) return launch_head_bf16_stream(a, s);
+    }
     static bool attr_set[64] = {};
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);

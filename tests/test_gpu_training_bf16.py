@@ -296,3 +296,27 @@ def test_pretrain_steps_bf16_reduce_the_loss_like_the_fp32_step():
         assert losses[-1] < losses[0]
     print("loss after 12 steps: fp32", finals["fp32"][-1], "bf16", finals["bf16"][-1])
     assert abs(finals["bf16"][-1] - finals["fp32"][-1]) <= 2e-3 * abs(finals["fp32"][-1])
+
+
+@pytest.mark.parametrize("n,bands", [(1, 0), (3, 1), (3, 2), (2, 3), (2, 5), (3, 8)])
+def test_head_bf16_row_streaming_kernel_vs_fp64_and_tile_kernel(n, bands, monkeypatch):
+    """The bf16 head (Generator.py:71,80) in its row-streaming form (srgen_head_bf16_stream.hip: bands of rows walked with a
+    ring of nine partial output rows) against conv2d in fp64 on the same bf16-rounded operands (fp32 accumulation over
+    7,776 products: bar 2e-6 of max) and against the tile kernel it replaces; every band count the launcher can pick
+    (band edges in the middle of the image, the last band's rows below the image, one band = no halo)."""
+    from superresolution_amd import training as T
+    vb, vf = _b(_nhwc(_hash_tensor(61, "hv", (n, 96, 128, 128))).cuda())
+    w = (_hash_tensor(62, "hw", (3, 96, 9, 9)) * 0.05).to(torch.bfloat16).float().cuda()
+    b = _hash_tensor(63, "hb", (3,)).cuda()
+    if bands:
+        monkeypatch.setenv("SRGEN_HEAD_BANDS", str(bands))
+    y = T.head_forward(vb, w, b)
+    monkeypatch.setenv("SRGEN_HEAD_BF16", "tile")
+    yt = T.head_forward(vb, w, b)
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.conv2d(vf.cpu().double().permute(0, 3, 1, 2), w.cpu().double(), b.cpu().double(), padding=4)[:, :, :125, :125]
+    scale = float(ref.abs().max())
+    e = float((y.cpu().double() - ref).abs().max()) / scale
+    et = float((yt.cpu().double() - ref).abs().max()) / scale
+    print(f"  head bf16 (n {n}, bands {bands}): streaming {e:.2e}, tile {et:.2e} of max vs fp64")
+    assert e <= 2e-6 and et <= 2e-6, (e, et)
