@@ -22,6 +22,8 @@
 // writes sit between the chunk's two barriers.  A kernel row's weight fragments are re-loaded for the next chunk as
 // soon as its last product of the chunk is issued.
 #include "srgen_internal.h"
+#include <cstdlib>
+#include <cstring>
 
 namespace srgen {
 namespace hfs {
@@ -216,6 +218,10 @@ __global__ __launch_bounds__(NTHR, 1) void head_f32s_kernel(HeadArgs a)
 hipError_t launch_head_f32_split(const HeadArgs& a, hipStream_t s)
 {
     using namespace hfs;
+    {
+        const char* e = getenv("SRGEN_HEAD_F32S");            // development switch, read per call: "tile" = this file's kernel
+        if (!(e && !strcmp(e, "tile"))) return launch_head_f32_split_stream(a, s);
+    }
     static bool attr_set[64] = {};      // per device: > 64 KB dynamic LDS needs the opt-in once
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);

@@ -218,6 +218,7 @@ hipError_t launch_stem_split_pack(const float* wm, int flip, void* out, hipStrea
 hipError_t launch_head_f32(const HeadArgs& a, hipStream_t s);
 // the head on the split path (srgen_head_f32s.hip); wpack = f16 units [chunk 6][ky 9][hi | lo][lane 64]
 hipError_t launch_head_f32_split(const HeadArgs& a, hipStream_t s);
+hipError_t launch_head_f32_split_stream(const HeadArgs& a, hipStream_t s);   // srgen_head_f32s_stream.hip
 // bf16 kernels (srgen_kernels_bf16.hip)
 hipError_t launch_stem_bf16(const StemArgs& a, hipStream_t s);
 hipError_t launch_conv3x3_bf16(const Conv3x3Args& a, hipStream_t s);

@@ -638,3 +638,33 @@ def test_two_stream_backward_is_bit_identical_to_one_stream(monkeypatch):
         flats[mode] = out
     for a, b in zip(flats["0"], flats["1"]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("n,bands,scale", [(1, 0, 1.0), (3, 1, 1.0), (3, 2, 1.0), (2, 3, 2.0 ** -20), (2, 5, 1.0), (3, 8, 300.0)])
+def test_head_fp32_row_streaming_kernel_vs_fp64_and_tile_kernel(n, bands, scale, monkeypatch):
+    """The fp32 head on split-f16 products (Generator.py:71,80) in its row-streaming form (srgen_head_f32s_stream.hip: pixels
+    split in registers a row ahead, all weight fragments in LDS, ring of nine partial output rows) against conv2d in fp64
+    and against the tile kernel it replaces, at every band count the launcher can pick.  Inputs of order `scale`: the
+    training-op entry point passes no input bound, so only order-1 inputs keep fp32 accuracy (bar 3e-6 of max, the tile
+    kernel's); the scaled cases check that both kernels degrade alike (same split, same products)."""
+    from superresolution_amd import training as T
+    v = (_nhwc(_hash_tensor(71, "hv", (n, 96, 128, 128))) * scale).cuda()
+    w = (_hash_tensor(72, "hw", (3, 96, 9, 9)) * 0.05).cuda()
+    b = _hash_tensor(73, "hb", (3,)).cuda()
+    if bands:
+        monkeypatch.setenv("SRGEN_HEAD_BANDS", str(bands))
+    with T.conv_precision("fp32"):
+        y = T.head_forward(v, w, b)
+        monkeypatch.setenv("SRGEN_HEAD_F32S", "tile")
+        yt = T.head_forward(v, w, b)
+    torch.cuda.synchronize()
+    ref = F.conv2d(v.cpu().double().permute(0, 3, 1, 2), w.cpu().double(), None, padding=4)[:, :, :125, :125]
+    sc = float(ref.abs().max())
+    bb = b.cpu().double().view(1, 3, 1, 1)
+    e = float((y.cpu().double() - bb - ref).abs().max()) / sc
+    et = float((yt.cpu().double() - bb - ref).abs().max()) / sc
+    print(f"  head fp32 split (n {n}, bands {bands}, scale {scale:g}): streaming {e:.2e}, tile {et:.2e} of max vs fp64")
+    if scale == 1.0:
+        assert e <= 3e-6 and et <= 3e-6, (e, et)
+    else:
+        assert e <= 2.0 * et + 1e-6, (e, et)
