@@ -32,8 +32,11 @@ constexpr int PLANE = ROWS * RS * 8;               // bytes of one (high | low) 
 constexpr int NVAL = 3 * ROWS * RS;                // input values of a tile: 2,736
 constexpr int PER_THREAD = (NVAL + 255) / 256;     // ... per thread: 11
 
-// OUT_BF16: the NHWC output is stored as bf16 (the 16-bit training step), 8-byte pieces
-template <bool OUT_BF16>
+// OUT_BF16: the NHWC output is stored as bf16 (the 16-bit training step), 8-byte pieces.  TERMS = 1 (with OUT_BF16 only): the
+// operands rounded to f16 after the range scaling, ONE MFMA per product -- the 16-bit step's arithmetic class (the reference
+// runs these convs under bf16 autocast, train.py:91: operands rounded to 8 significant bits; f16 keeps 11), a third of the
+// matrix work: the head's data gradient at 128 x 128 was the step's largest 9x9 kernel (240 us of MFMAs for 40 us of stores)
+template <bool OUT_BF16, int TERMS = 3>
 __global__ __launch_bounds__(256, 2) void stem_f32s_kernel(Stem9Args a)
 {
     __shared__ __attribute__((aligned(16))) char lds[2 * PLANE];
@@ -78,7 +81,7 @@ __global__ __launch_bounds__(256, 2) void stem_f32s_kernel(Stem9Args a)
             const float s = v[k] * in_mul;
             const _Float16 hi = (_Float16)s;
             hi_plane[(r * RS + cc) * 4 + c] = hi;
-            lo_plane[(r * RS + cc) * 4 + c] = (_Float16)(s - (float)hi);
+            if (TERMS == 3) lo_plane[(r * RS + cc) * 4 + c] = (_Float16)(s - (float)hi);
         }
     }
     __syncthreads();
@@ -103,22 +106,26 @@ __global__ __launch_bounds__(256, 2) void stem_f32s_kernel(Stem9Args a)
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 const h4 a0 = *(const h4*)(xb + 32 * 8 * mt), a1 = *(const h4*)(xb + 32 * 8 * mt + 8);
-                const h4 b0 = *(const h4*)(xb + PLANE + 32 * 8 * mt), b1 = *(const h4*)(xb + PLANE + 32 * 8 * mt + 8);
                 xh[mt] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
-                xl[mt] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+                if (TERMS == 3) {
+                    const h4 b0 = *(const h4*)(xb + PLANE + 32 * 8 * mt), b1 = *(const h4*)(xb + PLANE + 32 * 8 * mt + 8);
+                    xl[mt] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
             }
             h8 wh[3], wl[3];
 #pragma unroll
             for (int nt = 0; nt < 3; ++nt) {
                 wh[nt] = wp[(((ky * 3 + s) * 3 + nt) * 2 + 0) * 64];
-                wl[nt] = wp[(((ky * 3 + s) * 3 + nt) * 2 + 1) * 64];
+                if (TERMS == 3) wl[nt] = wp[(((ky * 3 + s) * 3 + nt) * 2 + 1) * 64];
             }
 #pragma unroll
             for (int nt = 0; nt < 3; ++nt)
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {          // small terms first
-                    acc[mt][nt] = MFMA_H(wl[nt], xh[mt], acc[mt][nt]);
-                    acc[mt][nt] = MFMA_H(wh[nt], xl[mt], acc[mt][nt]);
+                    if (TERMS == 3) {
+                        acc[mt][nt] = MFMA_H(wl[nt], xh[mt], acc[mt][nt]);
+                        acc[mt][nt] = MFMA_H(wh[nt], xl[mt], acc[mt][nt]);
+                    }
                     acc[mt][nt] = MFMA_H(wh[nt], xh[mt], acc[mt][nt]);
                 }
         }
@@ -157,6 +164,143 @@ __global__ __launch_bounds__(256, 2) void stem_f32s_kernel(Stem9Args a)
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
         if (lane == 0 && vmax == vmax) atomicMax((unsigned*)a.out_amax + n, __float_as_uint(vmax));
+    }
+}
+
+// ---- the 16-bit step's form: ONE term, weights resident in LDS, persistent workgroups --------------------------------------
+// The kernel above reads its weight fragments from L2 inside the k loop (81 or 162 16-byte loads per lane and tile, each
+// k step behind the latency of its own loads): 31 us per workgroup for 1.2 us of MFMAs -- the head's data gradient of the
+// 16-bit step (64 images, 128 x 128) took 250 us whether it ran one or three terms.  With one term the 81 high-part
+// fragments are 81 KB: a persistent workgroup (one per CU) copies them to LDS once and walks tiles, the next tile's input
+// values in registers under the current tile's MFMAs, two input planes alternating; per tile: 81 MFMAs per wave against
+// 189 LDS reads (the LDS array, then the stores, bound it).  Arithmetic: operands rounded to f16 after the power-of-two range
+// scaling, ONE v_mfma_f32_32x32x16_f16 per product -- the reference runs these convs under bf16 autocast (train.py:91:
+// operands rounded to 8 significant bits; f16 keeps 11).
+constexpr int WL_BYTES = 81 * 1024;
+constexpr int LDS1_BYTES = WL_BYTES + 2 * PLANE;          // 97,536
+
+template <bool OUT_BF16>
+__global__ __launch_bounds__(256, 1) void stem_f16_lds_kernel(Stem9Args a, int total_tiles)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    __shared__ float red[2][4];
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, p = lane & 31;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_x = a.ow >> 6, tiles_y = a.oh >> 2;
+
+    {   // high-part units of the packed image ([ky 9][s 3][nt 3][hi | lo][lane 64]) -> LDS [ky][s][nt][lane]; planes zeroed once
+        const h8* wg = (const h8*)a.wpack;               // (the unused fourth channel of a pixel stays 0 for good)
+        for (int i = tid; i < 81 * 64; i += 256) *(h8*)(lds + i * 16) = wg[((i >> 6) * 2) * 64 + (i & 63)];
+        for (int i = tid; i < 2 * PLANE / 4; i += 256) ((unsigned*)(lds + WL_BYTES))[i] = 0u;
+    }
+    const int kw = split_tail_exp((const char*)a.wpack + kStemSplitHalfs * 2, lane);
+
+    float v[PER_THREAD];
+    auto load_tile = [&](int t) {                        // -> v (nothing here may USE v: the loads stay in flight under the MFMAs)
+        const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, n = t / (tiles_x * tiles_y);
+        const int y0 = ty * 4, x0 = tx * 64;
+        const float* x = a.x + (size_t)n * 3 * a.ih * a.iw;
+#pragma unroll
+        for (int k = 0; k < PER_THREAD; ++k) {
+            const int i = tid + 256 * k;
+            const int cc = i % RS, r = (i / RS) % ROWS, c = i / (RS * ROWS);
+            const int gy = y0 - 4 + r, gx = x0 - 4 + cc;
+            const bool ok = i < NVAL && (unsigned)gy < (unsigned)a.ih && (unsigned)gx < (unsigned)a.iw;
+            v[k] = ok ? x[((size_t)c * a.ih + gy) * a.iw + gx] : 0.f;
+        }
+    };
+
+    int t = blockIdx.x, b = 0;
+    if (t < total_tiles) load_tile(t);
+    for (; t < total_tiles; t += gridDim.x, b ^= 1) {
+        const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, n = t / (tiles_x * tiles_y);
+        const int y0 = ty * 4, x0 = tx * 64;
+        // ---- this tile's bound, its f16 plane ----
+        float m = 0.f;
+#pragma unroll
+        for (int k = 0; k < PER_THREAD; ++k) m = fmaxf(m, fabsf(v[k]));
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if (lane == 0) red[b][w] = m;
+        __syncthreads();                                  // (also: every wave is past the MFMAs of the tile before)
+        const int kx_in = __builtin_amdgcn_readfirstlane(split_exp(fmaxf(fmaxf(red[b][0], red[b][1]), fmaxf(red[b][2], red[b][3]))));
+        const float in_mul = pow2f(kx_in), out_mul = pow2f(-(kw + kx_in));
+        _Float16* const plane = (_Float16*)(lds + WL_BYTES + b * PLANE);
+#pragma unroll
+        for (int k = 0; k < PER_THREAD; ++k) {
+            const int i = tid + 256 * k;
+            if (i < NVAL) {
+                const int cc = i % RS, r = (i / RS) % ROWS, c = i / (RS * ROWS);
+                plane[(r * RS + cc) * 4 + c] = (_Float16)(v[k] * in_mul);
+            }
+        }
+        __syncthreads();
+        // ---- the next tile's values on their way under this tile's MFMAs ----
+        const int tn = t + gridDim.x;
+        if (tn < total_tiles) load_tile(tn);
+
+        f32x16 acc[2][3];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+        const char* const wl = lds + lane * 16;
+#pragma unroll
+        for (int ky = 0; ky < 9; ++ky) {
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const char* xb = (const char*)plane + ((w + ky) * RS + p + 4 * s + 2 * h) * 8;
+                h8 xh[2], wh[3];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const h4 a0 = *(const h4*)(xb + 32 * 8 * mt), a1 = *(const h4*)(xb + 32 * 8 * mt + 8);
+                    xh[mt] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+#pragma unroll
+                for (int nt = 0; nt < 3; ++nt) wh[nt] = *(const h8*)(wl + ((ky * 3 + s) * 3 + nt) * 1024);
+#pragma unroll
+                for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) acc[mt][nt] = MFMA_H(wh[nt], xh[mt], acc[mt][nt]);
+            }
+        }
+
+        // ---- epilogue (registers only): scale back, bias, PReLU, NHWC stores, per-image maximum ----
+        const size_t out_off = (((size_t)n * a.oh + y0 + w) * a.ow + x0 + p) * kC + 4 * h;
+        float* out = a.out + out_off;
+        bf16_t* outb = (bf16_t*)a.out + out_off;
+        float vmax = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+            for (int G = 0; G < 4; ++G) {
+                f32x4 b4 = {0.f, 0.f, 0.f, 0.f}, s4 = {1.f, 1.f, 1.f, 1.f};
+                if (a.bias) b4 = *(const f32x4*)(a.bias + 32 * nt + 8 * G + 4 * h);
+                if (a.slope) s4 = *(const f32x4*)(a.slope + 32 * nt + 8 * G + 4 * h);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float tt = acc[mt][nt][4 * G + e] * out_mul + b4[e];
+                        o[e] = tt >= 0.f ? tt : tt * s4[e];
+                        vmax = fmaxf(vmax, fabsf(o[e]));
+                    }
+                    if constexpr (OUT_BF16) {
+                        const float o4[4] = {o[0], o[1], o[2], o[3]};
+                        st4(outb + (size_t)(32 * mt) * kC + 32 * nt + 8 * G, o4);
+                    } else {
+                        *(f32x4*)(out + (size_t)(32 * mt) * kC + 32 * nt + 8 * G) = o;
+                    }
+                }
+            }
+        if (a.out_amax) {
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+            if (lane == 0 && vmax == vmax) atomicMax((unsigned*)a.out_amax + n, __float_as_uint(vmax));
+        }
     }
 }
 
@@ -209,7 +353,23 @@ hipError_t launch_conv9x9_c3_split(const Stem9Args& a, hipStream_t s)
     if (a.N <= 0 || a.ih <= 0 || a.iw <= 0 || a.oh <= 0 || a.ow <= 0 || (a.oh & 3) || (a.ow & 63)) return hipErrorInvalidValue;
     const long long blocks = (long long)a.N * (a.oh >> 2) * (a.ow >> 6);
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    if (a.out_bf16) hipLaunchKernelGGL(sfs::stem_f32s_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    if (a.out_bf16) {                                 // the 16-bit step: one term, weights in LDS, one persistent workgroup per CU
+        static bool attr_set[64] = {};
+        static int cu_count[64] = {};
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+            int cus = 0;
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && dev >= 0 && dev < 64) cu_count[dev] = cus;
+            e = hipFuncSetAttribute((const void*)sfs::stem_f16_lds_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, sfs::LDS1_BYTES);
+            if (e != hipSuccess) return e;
+            if (dev >= 0 && dev < 64) attr_set[dev] = true;
+        }
+        const int cus = (dev >= 0 && dev < 64 && cu_count[dev] > 0) ? cu_count[dev] : 256;
+        const unsigned grid = (unsigned)(blocks < cus ? blocks : cus);
+        hipLaunchKernelGGL(sfs::stem_f16_lds_kernel<true>, dim3(grid), dim3(256), sfs::LDS1_BYTES, s, a, (int)blocks);
+    }
     else hipLaunchKernelGGL(sfs::stem_f32s_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, a);
     return hipGetLastError();
 }
