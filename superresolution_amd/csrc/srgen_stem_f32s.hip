@@ -16,6 +16,8 @@
 // any input size (zero outside), output a multiple of 4 rows x 64 columns, optional bias / PReLU, and a weight image packed
 // on the device from the [243][96] tap matrix (stem_split_pack_kernel; the flip is a permutation of the taps there).
 #include "srgen_internal.h"
+#include <cstdlib>
+#include <cstring>
 
 namespace srgen {
 namespace sfs {
@@ -132,6 +134,174 @@ __global__ __launch_bounds__(256, 2) void stem_f32s_kernel(Stem9Args a)
     }
 
     // ---- epilogue (registers only): scale back, bias, PReLU, 16-byte NHWC stores, per-image maximum -----------------------
+    const size_t out_off = (((size_t)n * a.oh + y0 + w) * a.ow + x0 + p) * kC + 4 * h;
+    float* out = a.out + out_off;
+    bf16_t* outb = (bf16_t*)a.out + out_off;
+    float vmax = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+        for (int G = 0; G < 4; ++G) {
+            f32x4 b4 = {0.f, 0.f, 0.f, 0.f}, s4 = {1.f, 1.f, 1.f, 1.f};
+            if (a.bias) b4 = *(const f32x4*)(a.bias + 32 * nt + 8 * G + 4 * h);
+            if (a.slope) s4 = *(const f32x4*)(a.slope + 32 * nt + 8 * G + 4 * h);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t = acc[mt][nt][4 * G + e] * out_mul + b4[e];
+                    o[e] = t >= 0.f ? t : t * s4[e];
+                    vmax = fmaxf(vmax, fabsf(o[e]));
+                }
+                if constexpr (OUT_BF16) {
+                    const float o4[4] = {o[0], o[1], o[2], o[3]};
+                    st4(outb + (size_t)(32 * mt) * kC + 32 * nt + 8 * G, o4);
+                } else {
+                    *(f32x4*)(out + (size_t)(32 * mt) * kC + 32 * nt + 8 * G) = o;
+                }
+            }
+        }
+    if (a.out_amax) {                                 // non-negative floats order like their bit patterns
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+        if (lane == 0 && vmax == vmax) atomicMax((unsigned*)a.out_amax + n, __float_as_uint(vmax));
+    }
+}
+
+// ---- the three-term kernel with its weights on an LDS ring ---------------------------------------------------------------
+// stem_f32s_kernel reads a k step's six weight fragments from L2 right where it multiplies them, and the compiler cannot
+// hoist 162 loads far enough: 31 us per workgroup for 3.7 us of MFMAs (0.29 ms per batch-256 launch).  Here the weights of
+// one kernel row (3 s x 3 nt x {hi, lo} = 18 KB) are a slab copied global -> LDS without registers (global_load_lds), two
+// kernel rows ahead, into a three-slot ring; one barrier per kernel row; fragments come from LDS.  Same products, same order
+// per accumulator: bit-identical to stem_f32s_kernel.  68.6 KB of LDS: two workgroups per CU.
+constexpr int SLAB = 18 * 1024;
+constexpr int RING_OFF = 2 * PLANE;                       // ring behind the two input planes
+constexpr int LDSR_BYTES = RING_OFF + 3 * SLAB;           // 69,888
+
+__device__ __forceinline__ void glds16_raw(const void* sbase, unsigned voff, unsigned lds_addr)
+{
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :: "v"(voff), "s"(sbase), "s"(lds_addr) : "memory", "m0");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm_only()
+{
+    __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
+    asm volatile("" ::: "memory");
+}
+
+template <bool OUT_BF16>
+__global__ __launch_bounds__(256, 2) void stem_f32s_ring_kernel(Stem9Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    __shared__ float red[4];
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, p = lane & 31;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_x = a.ow >> 6, tiles_y = a.oh >> 2;
+    int b = blockIdx.x;
+    const int tx = b % tiles_x;
+    b /= tiles_x;
+    const int ty = b % tiles_y, n = b / tiles_y;
+    const int y0 = ty * 4, x0 = tx * 64;
+    const float* x = a.x + (size_t)n * 3 * a.ih * a.iw;
+
+    // slab ky: pieces 0 .. 17 of 1 KB; wave w copies pieces w, w + 4, ... (waves 0, 1: five, waves 2, 3: four)
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+    const unsigned lane16 = (unsigned)lane * 16u;
+    const int npc = w < 2 ? 5 : 4;
+    auto issue_slab = [&](int ky) {
+        const char* src = (const char*)a.wpack + (size_t)ky * SLAB;
+        const unsigned dst = lds_base + RING_OFF + (ky % 3) * SLAB;
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+            if (k < npc) glds16_raw(src + (w + 4 * k) * 1024, lane16, dst + (w + 4 * k) * 1024);
+    };
+    issue_slab(0);
+    issue_slab(1);
+
+    // ---- input tile: load, bound, split, HWC4 planes (as stem_f32s_kernel) ----
+    float v[PER_THREAD];
+    float m = 0.f;
+#pragma unroll
+    for (int k = 0; k < PER_THREAD; ++k) {
+        const int i = tid + 256 * k;
+        const int cc = i % RS, r = (i / RS) % ROWS, c = i / (RS * ROWS);
+        const int gy = y0 - 4 + r, gx = x0 - 4 + cc;
+        const bool ok = i < NVAL && (unsigned)gy < (unsigned)a.ih && (unsigned)gx < (unsigned)a.iw;
+        v[k] = ok ? x[((size_t)c * a.ih + gy) * a.iw + gx] : 0.f;
+        m = fmaxf(m, fabsf(v[k]));
+    }
+    for (int i = tid; i < 2 * PLANE / 4; i += 256) ((unsigned*)lds)[i] = 0u;          // (the unused fourth channel must be 0)
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0) red[w] = m;
+    __syncthreads();
+    const int kx_in = __builtin_amdgcn_readfirstlane(split_exp(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
+    const int kw = split_tail_exp((const char*)a.wpack + kStemSplitHalfs * 2, lane);
+    const float in_mul = pow2f(kx_in), out_mul = pow2f(-(kw + kx_in));
+    _Float16* const hi_plane = (_Float16*)lds;
+    _Float16* const lo_plane = (_Float16*)(lds + PLANE);
+#pragma unroll
+    for (int k = 0; k < PER_THREAD; ++k) {
+        const int i = tid + 256 * k;
+        if (i < NVAL) {
+            const int cc = i % RS, r = (i / RS) % ROWS, c = i / (RS * ROWS);
+            const float sv = v[k] * in_mul;
+            const _Float16 hi = (_Float16)sv;
+            hi_plane[(r * RS + cc) * 4 + c] = hi;
+            lo_plane[(r * RS + cc) * 4 + c] = (_Float16)(sv - (float)hi);
+        }
+    }
+
+    f32x16 acc[2][3];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+#pragma unroll 1
+    for (int ky = 0; ky < 9; ++ky) {
+        // this wave's pieces of slab ky have landed (only the pieces of slab ky + 1 may still be on their way: copies retire
+        // in order, and the input loads above are older than every copy that matters here)
+        if (ky + 1 < 9) { if (w < 2) wait_vm_only<5>(); else wait_vm_only<4>(); }
+        else wait_vm_only<0>();
+        __builtin_amdgcn_s_waitcnt(0xC07F);               // lgkmcnt(0): the planes (ky = 0), this wave's reads of slab ky - 1
+        __builtin_amdgcn_s_barrier();                     // slab ky complete; every wave is past slab ky - 1
+        asm volatile("" ::: "memory");
+        if (ky + 2 < 9) issue_slab(ky + 2);               // into the slot of slab ky - 1
+        const char* const wl = lds + RING_OFF + (ky % 3) * SLAB + lane * 16;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const char* xb = lds + ((w + ky) * RS + p + 4 * s + 2 * h) * 8;
+            h8 xh[2], xl[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const h4 a0 = *(const h4*)(xb + 32 * 8 * mt), a1 = *(const h4*)(xb + 32 * 8 * mt + 8);
+                const h4 b0 = *(const h4*)(xb + PLANE + 32 * 8 * mt), b1 = *(const h4*)(xb + PLANE + 32 * 8 * mt + 8);
+                xh[mt] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+                xl[mt] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+            h8 wh[3], wlo[3];
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt) {
+                wh[nt] = *(const h8*)(wl + ((s * 3 + nt) * 2 + 0) * 1024);
+                wlo[nt] = *(const h8*)(wl + ((s * 3 + nt) * 2 + 1) * 1024);
+            }
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {          // small terms first (the order of stem_f32s_kernel)
+                    acc[mt][nt] = MFMA_H(wlo[nt], xh[mt], acc[mt][nt]);
+                    acc[mt][nt] = MFMA_H(wh[nt], xl[mt], acc[mt][nt]);
+                    acc[mt][nt] = MFMA_H(wh[nt], xh[mt], acc[mt][nt]);
+                }
+        }
+    }
+
+    // ---- epilogue (registers only): scale back, bias, PReLU, 16-byte NHWC stores, per-image maximum ----
     const size_t out_off = (((size_t)n * a.oh + y0 + w) * a.ow + x0 + p) * kC + 4 * h;
     float* out = a.out + out_off;
     bf16_t* outb = (bf16_t*)a.out + out_off;
@@ -370,7 +540,24 @@ hipError_t launch_conv9x9_c3_split(const Stem9Args& a, hipStream_t s)
         const unsigned grid = (unsigned)(blocks < cus ? blocks : cus);
         hipLaunchKernelGGL(sfs::stem_f16_lds_kernel<true>, dim3(grid), dim3(256), sfs::LDS1_BYTES, s, a, (int)blocks);
     }
-    else hipLaunchKernelGGL(sfs::stem_f32s_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    else {
+        const char* ev = getenv("SRGEN_STEM_F32S");       // development switch, read per call: "direct" = weights straight from L2
+        if (ev && !strcmp(ev, "direct")) {
+            hipLaunchKernelGGL(sfs::stem_f32s_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+        } else {
+            static bool ring_attr[64] = {};
+            int dev = 0;
+            hipError_t e = hipGetDevice(&dev);
+            if (e != hipSuccess) return e;
+            if (dev < 0 || dev >= 64 || !ring_attr[dev]) {
+                e = hipFuncSetAttribute((const void*)sfs::stem_f32s_ring_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        sfs::LDSR_BYTES);
+                if (e != hipSuccess) return e;
+                if (dev >= 0 && dev < 64) ring_attr[dev] = true;
+            }
+            hipLaunchKernelGGL(sfs::stem_f32s_ring_kernel<false>, dim3((unsigned)blocks), dim3(256), sfs::LDSR_BYTES, s, a);
+        }
+    }
     return hipGetLastError();
 }
 

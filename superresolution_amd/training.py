@@ -706,7 +706,8 @@ def prelu_scalar_bwd(x, dy, slope, ws: Workspace, dy2=None, unshuffle: bool = Fa
 def conv9x9_c3(img: torch.Tensor, wm: torch.Tensor, bias, out_hw: int, flip: bool,
                out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
     """out (n, out_hw, out_hw, 96) NHWC = bias + sum over the 243 taps of a 3-channel NCHW image times ``wm`` [243][96].
-    ``out_dtype`` bfloat16 (the 16-bit step): the same fp32-accurate sums, rounded once when stored."""
+    ``out_dtype`` bfloat16 (the 16-bit step): products of the operands rounded to f16 (one MFMA per product: the arithmetic
+    class of the reference's autocast convs, 11 significant bits instead of bf16's 8), fp32 sums rounded once when stored."""
     n, c, ih, iw = img.shape
     assert c == 3 and img.is_contiguous() and wm.shape == (243, 96) and wm.is_contiguous()
     out = torch.empty((n, out_hw, out_hw, 96), dtype=out_dtype, device=img.device)

@@ -668,3 +668,20 @@ def test_head_fp32_row_streaming_kernel_vs_fp64_and_tile_kernel(n, bands, scale,
         assert e <= 3e-6 and et <= 3e-6, (e, et)
     else:
         assert e <= 2.0 * et + 1e-6, (e, et)
+
+
+@pytest.mark.parametrize("n,ih,out_hw,flip", [(3, 64, 64, False), (2, 125, 128, True)])
+def test_conv9x9_split_kernel_with_weights_on_an_lds_ring_is_bit_identical(n, ih, out_hw, flip, monkeypatch):
+    """The three-term 9x9 conv against a 3-channel image (eval stem Generator.py:50-51, head data gradient of the fp32 /
+    f16 steps) with its weight slabs copied to an LDS ring (stem_f32s_ring_kernel) multiplies the same products in the same
+    order per accumulator as the kernel that reads them from L2 (SRGEN_STEM_F32S=direct): equal bit for bit."""
+    from superresolution_amd import training as T
+    img = (_hash_tensor(81, "i", (n, 3, ih, ih)) * (2.0 ** -14 if flip else 1.0)).cuda()
+    wm = (_hash_tensor(82, "w", (243, 96)) * 0.1).cuda()
+    bias = None if flip else _hash_tensor(83, "b", (96,)).cuda()
+    y = T.conv9x9_c3(img, wm, bias, out_hw, flip)
+    monkeypatch.setenv("SRGEN_STEM_F32S", "direct")
+    yd = T.conv9x9_c3(img, wm, bias, out_hw, flip)
+    torch.cuda.synchronize()
+    assert float(y.abs().max()) > 0
+    assert torch.equal(y, yd)
