@@ -79,7 +79,8 @@ constexpr int A_BYTES = HH * HWP * PS;            // 44,352
 constexpr int SLAB = 6 * 96 * 16;                 // 9,216: one (tap, chunk) weight slab
 constexpr int NRING = 3;
 constexpr int BS_OFF = A_BYTES + NRING * SLAB;    // bias[4][96], slope[4][96] (fp32)
-constexpr int LDS_BYTES = BS_OFF + 2 * 4 * 96 * 4;   // 75,072 (two workgroups per CU)
+constexpr int RS_OFF = BS_OFF + 2 * 4 * 96 * 4;  // residual scales of the current / next item's image: [2][96] (fp32)
+constexpr int LDS_BYTES = RS_OFF + 2 * 96 * 4;    // 75,840 (two workgroups per CU)
 constexpr int MAX_WGS = 512;                      // persistent grid: 2 workgroups x 256 CUs
 
 struct Frags { bf16x8 a0, a1, b0, b1, b2; };
@@ -165,7 +166,10 @@ __device__ __forceinline__ void swap32(unsigned& x, unsigned& y)
 // halo rows two neighbouring tiles share then come from that XCD's L2.  Speed only.
 struct Item { int n, ty, tx, cb; };
 
-template <int HW, bool SHUFFLE, bool POOL, bool RES>
+// SC: a channel attention folded into this conv (eval forward: the block behind an attention, Generator.py:76-78):
+// 1 = the INPUT is multiplied by a.in_scale[n][ci] when its halo tile is stored to LDS, 2 = the RESIDUAL by
+// a.res_scale[n][co] in the epilogue -- each product rounded to bf16, exactly what the attention's in-place pass stored
+template <int HW, bool SHUFFLE, bool POOL, bool RES, int SC = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(Conv3x3Args a, int nitems)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -218,7 +222,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(Conv3x3Args a, int
         a_wtb |= (wrap ? 1u : 0u) << it | (r == 0 ? 1u : 0u) << (10 + it) | (r == HH - 1 ? 1u : 0u) << (20 + it);
         a_col |= (used ? 0u : 1u) << it | (cc == 0 ? 1u : 0u) << (10 + it) | (cc == HWP - 1 ? 1u : 0u) << (20 + it);
     }
+    f32x4 sstage[2];                      // SC == 1: the scales of this thread's 8 channels of the chunk in `stage`
     auto load_a = [&](const Item& t, int c) {
+        if (SC == 1) {
+            const float* sp = a.in_scale + (size_t)t.n * kC + c * CK + q6 * 8;
+            sstage[0] = *(const f32x4*)sp;
+            sstage[1] = *(const f32x4*)(sp + 4);
+        }
         const __bf16* in = (const __bf16*)a.in + (size_t)t.n * HW * HW * kC;
         const int x0 = t.tx * TW, y0 = t.ty * TH;
         // rounds whose pixel is outside the image (or unused): zero
@@ -243,7 +253,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(Conv3x3Args a, int
         if (tid < 252) {
 #pragma unroll
             for (int it = 0; it < 10; ++it)
-                if (it < 9 || p0 + 42 * 9 < HH * HWP) *(u32x4*)(a_l0 + it * 42 * PS) = stage[it];
+                if (it < 9 || p0 + 42 * 9 < HH * HWP) {
+                    u32x4 v = stage[it];
+                    if (SC == 1) {                // (zero pieces stay zero)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            v[j] = pack_bf16(bf16_lo(v[j]) * sstage[j >> 1][2 * (j & 1)], bf16_hi(v[j]) * sstage[j >> 1][2 * (j & 1) + 1]);
+                    }
+                    *(u32x4*)(a_l0 + it * 42 * PS) = v;
+                }
         }
     };
     // async slab copy, 576 x 16 B, slab j = (tap j%9, chunk j/9) of cout block cb into ring
@@ -281,6 +299,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(Conv3x3Args a, int
         ldsBias[i] = a.bias[i];
         ldsSlope[i] = act ? a.slope[i] : 1.f;
     }
+    float* const ldsRS = (float*)(lds + RS_OFF);
+    int rsb = 0;                                  // buffer of the current item's residual scales
+    if (SC == 2 && tid < kC) ldsRS[tid] = a.res_scale[(size_t)cur.n * kC + tid];
     // De-phase the two workgroups that share a CU (the first half of the grid is dealt one per
     // CU before the second half doubles up): while one is in its epilogue / staging the other
     // has the matrix pipe to itself.  Speed only.
@@ -413,6 +434,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(Conv3x3Args a, int
                         // loaded piece = [X0 X1 Y0 Y1] in the stored (swapped) arrangement: undo it
                         swap32(r0, r2);
                         swap32(r1, r3);
+                        if (SC == 2) {            // registers 8P + k: channel 32 nt + 16 P + 8 (k >> 2) + 4 h + (k & 3)
+                            const float* rs = ldsRS + rsb * kC + 32 * nt + 16 * P + 4 * h;
+                            const f32x4 sa = *(const f32x4*)rs, sb = *(const f32x4*)(rs + 8);
+                            r0 = pack_bf16(bf16_lo(r0) * sa[0], bf16_hi(r0) * sa[1]);
+                            r1 = pack_bf16(bf16_lo(r1) * sa[2], bf16_hi(r1) * sa[3]);
+                            r2 = pack_bf16(bf16_lo(r2) * sb[0], bf16_hi(r2) * sb[1]);
+                            r3 = pack_bf16(bf16_lo(r3) * sb[2], bf16_hi(r3) * sb[3]);
+                        }
                         c[8 * P + 0] += bf16_lo(r0); c[8 * P + 1] += bf16_hi(r0);
                         c[8 * P + 2] += bf16_lo(r1); c[8 * P + 3] += bf16_hi(r1);
                         c[8 * P + 4] += bf16_lo(r2); c[8 * P + 5] += bf16_hi(r2);
@@ -471,6 +500,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(Conv3x3Args a, int
         C3_STAMP(5);
         if (!has_next) break;
         store_a();
+        if (SC == 2) {                            // (the other buffer: slower waves still read this item's)
+            rsb ^= 1;
+            if (tid < kC) ldsRS[rsb * kC + tid] = a.res_scale[(size_t)nx.n * kC + tid];
+        }
         wait_vm0();
         __syncthreads();                          // next A chunk 0 and its slabs 0, 1 are in LDS
         item = nxt;
@@ -478,7 +511,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(Conv3x3Args a, int
     }
 }
 
-template <int HW, bool SHUFFLE, bool POOL, bool RES>
+template <int HW, bool SHUFFLE, bool POOL, bool RES, int SC = 0>
 hipError_t launch_one(const Conv3x3Args& a, hipStream_t s)
 {
     static bool attr_set[64] = {};
@@ -486,14 +519,14 @@ hipError_t launch_one(const Conv3x3Args& a, hipStream_t s)
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        e = hipFuncSetAttribute((const void*)conv3x3_bf16_kernel<HW, SHUFFLE, POOL, RES>,
+        e = hipFuncSetAttribute((const void*)conv3x3_bf16_kernel<HW, SHUFFLE, POOL, RES, SC>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return e;
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
     const int nitems = a.N * (HW / TH) * (HW / TW) * (SHUFFLE ? 4 : 1);     // multiple of 16
     const int grid = nitems < MAX_WGS ? nitems & ~7 : MAX_WGS;
-    hipLaunchKernelGGL((conv3x3_bf16_kernel<HW, SHUFFLE, POOL, RES>), dim3((unsigned)grid), dim3(256), LDS_BYTES,
+    hipLaunchKernelGGL((conv3x3_bf16_kernel<HW, SHUFFLE, POOL, RES, SC>), dim3((unsigned)grid), dim3(256), LDS_BYTES,
                        s, a, nitems);
     return hipGetLastError();
 }
@@ -505,6 +538,14 @@ hipError_t launch_conv3x3_bf16(const Conv3x3Args& a, hipStream_t s)
     using namespace c3;
     if (a.H != a.W || a.N <= 0) return hipErrorInvalidValue;
     const bool res = a.res != nullptr, pool = a.pool_partial != nullptr;
+    if (a.in_scale && a.res_scale) return hipErrorInvalidValue;
+    if (a.in_scale || a.res_scale) {                  // a folded channel attention: the three convs that can sit behind one
+        if (a.H != kLR || a.shuffle || a.cout_blocks != 1 || pool) return hipErrorInvalidValue;
+        if (a.in_scale && !res) return launch_one<kLR, false, false, false, 1>(a, s);
+        if (a.in_scale && res) return launch_one<kLR, false, false, true, 1>(a, s);
+        if (a.res_scale && res) return launch_one<kLR, false, false, true, 2>(a, s);
+        return hipErrorInvalidValue;
+    }
     if (a.H == kLR && !a.shuffle && a.cout_blocks == 1) {
         if (!pool && !res) return launch_one<kLR, false, false, false>(a, s);
         if (!pool && res) return launch_one<kLR, false, false, true>(a, s);

@@ -189,7 +189,8 @@ __global__ __launch_bounds__(256) void chan_attn_bf16_kernel(ChanAttnArgs a)
 {
     __shared__ float s_pool[kC], s_hid[12], s_scale[kC];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int n = blockIdx.x / CAB_SLICES, slice = blockIdx.x % CAB_SLICES;
+    const int nsl = a.scale_only ? 1 : CAB_SLICES;
+    const int n = blockIdx.x / nsl, slice = blockIdx.x % nsl;
     if (tid < kC) {
         float s = 0.f;
         for (int t = 0; t < a.tiles; ++t) s += a.pool_partial[((size_t)n * a.tiles + t) * kC + tid];
@@ -212,6 +213,7 @@ __global__ __launch_bounds__(256) void chan_attn_bf16_kernel(ChanAttnArgs a)
     }
     __syncthreads();
     if (slice == 0 && tid < kC) a.scale_out[(size_t)n * kC + tid] = s_scale[tid];
+    if (a.scale_only) return;
     const int per_slice = a.hw * kC / 8 / CAB_SLICES;          // 16-byte pieces per slice
     u32x4* x = (u32x4*)a.x + (size_t)n * a.hw * kC / 8 + (size_t)slice * per_slice;
     for (int i = tid; i < per_slice; i += 256) {
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(256) void chan_attn_bf16_kernel(ChanAttnArgs a)
 hipError_t launch_chan_attn_bf16(const ChanAttnArgs& a, hipStream_t s)
 {
     if ((a.hw * kC / 8) % CAB_SLICES) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(chan_attn_bf16_kernel, dim3((unsigned)(a.N * CAB_SLICES)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(chan_attn_bf16_kernel, dim3((unsigned)(a.N * (a.scale_only ? 1 : CAB_SLICES))), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

@@ -538,3 +538,20 @@ def test_train_mode_forward_under_bf16_autocast():
     with torch.no_grad():
         yb2 = g(x.to(torch.bfloat16))                                    # bf16 input without autocast
     assert yb2.dtype == torch.bfloat16
+
+
+@pytest.mark.parametrize("n", [1, 5, 19])
+def test_bf16_forward_with_the_channel_attention_folded_into_the_convs_is_bit_identical(gen, n, monkeypatch):
+    """bf16 eval forward (Generator.py:15-27,76-78): by default the two channel attentions only compute their scales and the
+    convs behind them multiply where they read (conv1's input tile when it is staged, conv2's residual in the epilogue, the
+    mid conv's input), rounding each product to bf16 as the attention's in-place pass did.  SRGEN_CA_FOLD=0 runs that pass:
+    the outputs must be equal bit for bit.  Distinct random images, batches that end inside a workgroup's item range."""
+    g = torch.Generator().manual_seed(123 + n)
+    x = torch.rand((n, 3, 64, 64), generator=g).cuda().to(torch.bfloat16)
+    with torch.no_grad():
+        y = gen(x)
+        monkeypatch.setenv("SRGEN_CA_FOLD", "0")
+        y0 = gen(x)
+    torch.cuda.synchronize()
+    assert y.dtype == torch.bfloat16 and float(y.float().abs().max()) > 0
+    assert torch.equal(y, y0)
