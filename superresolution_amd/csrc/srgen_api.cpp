@@ -809,11 +809,12 @@ static int run_forward(srgen_handle* h, const void* x, void* y, void* workspace,
     }
     const void* cur = x1;                               // x2 = blocks(x1)  Generator.py:76
     int flip = 0;
-    // bf16 eval forward: the attention's in-place pass over the tensor (2 x 75 us at 256 images) is not run -- its kernel
+    // eval forward (bf16, fp32 split path): the attention's in-place pass over the tensor (2 x 75 / 150 us at 256 images) is not run -- its kernel
     // leaves the scales only and the convs behind it (the next block's conv1 input and conv2 residual, or the mid conv's
     // input) multiply by them where they read, rounding each product to bf16 as the pass did: bit-identical outputs.
     // Not with taps (they want the scaled tensor); SRGEN_CA_FOLD=0 keeps the pass (what the test compares with)
-    bool fold_ca = bf && !train && !taps;
+    // (fp32: the split path's persistent kernel only -- 6 images or more)
+    bool fold_ca = !train && !taps && (bf || (h->f32_split && n * (kLR / 4) * (kLR / 64) >= 96));
     if (fold_ca) {
         const char* ev = getenv("SRGEN_CA_FOLD");
         if (ev && !strcmp(ev, "0")) fold_ca = false;

@@ -47,7 +47,8 @@ constexpr int WG_BYTES = WG_UNITS * 16;           // 18,432
 constexpr int W_OFF = A_BYTES;
 constexpr int BS_OFF = W_OFF + 2 * WG_BYTES;      // bias[4][96], slope[4][96]
 constexpr int POOL_OFF = BS_OFF + 2 * 4 * 96 * 4;
-constexpr int LDS_BYTES = POOL_OFF + 4 * 96 * 4;  // 73,152 (two workgroups per CU)
+constexpr int RS_OFF = POOL_OFF + 4 * 96 * 4;     // residual scales of the current / next item's image: [2][96] (a folded attention)
+constexpr int LDS_BYTES = RS_OFF + 2 * 96 * 4;    // 73,920 (two workgroups per CU)
 constexpr int A_ITEMS = HH * HWP * 4;             // float4 pieces per chunk (1,584)
 constexpr int A_REGS = 7;                         // ceil(1584 / 256)
 constexpr int MAX_WGS = 512;
@@ -81,7 +82,10 @@ __device__ __forceinline__ void mma_tap(f32x16 (&acc)[2][3], const Frags& f)
 struct Item { int n, ty, tx, cb; };
 
 // ABL: timing ablations for tools/bench_f32s.hip only (wrong results); the library instantiates ABL = 0
-template <int HW, bool SHUFFLE, bool POOL, bool RES, int ABL = 0, int TERMS = 3>
+// SC: a channel attention folded into this conv (eval forward, the block behind an attention -- Generator.py:76-78 -- as in
+// srgen_conv3x3_bf16.hip): 1 = every input piece is multiplied by a.in_scale[n][ci] before it is split, 2 = the residual by
+// a.res_scale[n][co] before it is added; one fp32 rounding each, the value the attention's in-place pass used to store
+template <int HW, bool SHUFFLE, bool POOL, bool RES, int ABL = 0, int TERMS = 3, int SC = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_f32s_kernel(Conv3x3Args a, int nitems)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -163,7 +167,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32s_kernel(Conv3x3Args a, int
             aok |= (ok ? 1u : 0u) << it;
         }
     };
+    f32x4 ssc = {1.f, 1.f, 1.f, 1.f};                 // SC == 1: the scales of this thread's four channels of the chunk in `stage`
     auto load_a = [&](const Item& t, int c) {
+        // (in FRONT of the pixel loads: the counted waits below leave the seven youngest loads in flight)
+        if (SC == 1) ssc = *(const f32x4*)(a.in_scale + (size_t)t.n * kC + c * CK + (tid & 3) * 4);
         const float* in = (const float*)a.in + (size_t)((ABL & 2048) ? 0 : t.n) * HW * HW * kC + c * CK;
 #pragma unroll
         for (int it = 0; it < A_REGS; ++it) stage[it] = *(const f32x4*)(in + aoff[it]);
@@ -174,7 +181,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32s_kernel(Conv3x3Args a, int
     auto convert_a = [&](int it) {
         const float m = ((aok >> it) & 1u) ? pow2f(kx_stage) : 0.f;
         unsigned h01, h23, l01 = 0, l23 = 0;      // (mixlo leaves the destination's high half for mixhi to fill: "=&v", then "+v")
-        const f32x4 v = stage[it];
+        f32x4 v = stage[it];
+        if (SC == 1) v *= ssc;                        // (a product of its own, rounded to fp32: what the attention pass stored)
         asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=&v"(h01) : "v"(v.x), "v"(m));
         asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h01) : "v"(v.y), "v"(m));
         asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=&v"(h23) : "v"(v.z), "v"(m));
@@ -248,6 +256,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32s_kernel(Conv3x3Args a, int
         ldsBias[i] = a.bias[i];
         ldsSlope[i] = act ? a.slope[i] : 1.f;
     }
+    float* const ldsRS = (float*)(lds + RS_OFF);
+    int rsb = 0;                                      // buffer of the current item's residual scales
+    if (SC == 2 && tid < kC) ldsRS[tid] = a.res_scale[(size_t)cur.n * kC + tid];
 #pragma unroll
     for (int it = 0; it < A_REGS; ++it) convert_a(it);
     store_a();
@@ -422,7 +433,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32s_kernel(Conv3x3Args a, int
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = v[e] >= 0.f ? v[e] : v[e] * s4[e];
                     }
-                    if (RES) v += rres[k][G];
+                    if (RES && SC == 2) {             // residual x scale, rounded, THEN added (no fused multiply-add)
+                        const f32x4 s4 = *(const f32x4*)(ldsRS + rsb * kC + 32 * nt + 8 * G + 4 * h);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float t = rres[k][G][e] * s4[e];
+                            asm volatile("" : "+v"(t));
+                            v[e] += t;
+                        }
+                    } else if (RES) v += rres[k][G];
                     vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
                     if (POOL) {
 #pragma unroll
@@ -467,6 +486,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32s_kernel(Conv3x3Args a, int
             if (lane == 0 && vmax == vmax) atomicMax((unsigned*)a.out_amax + cur.n, __float_as_uint(vmax));
         }
         if (!has_next) break;
+        if (SC == 2) {                                // (the other buffer: slower waves still read this item's; the next
+            rsb ^= 1;                                 // item's epilogue is eighteen barriers away)
+            if (tid < kC) ldsRS[rsb * kC + tid] = a.res_scale[(size_t)nx.n * kC + tid];
+        }
         item = nxt;
         cur = nx;
         kx_cur = kx_nx;
@@ -735,6 +758,19 @@ hipError_t launch_one(const Conv3x3Args& a, hipStream_t s)
 {
     const int nitems = a.N * (HW / TH) * (HW / TW) * (SHUFFLE ? 4 : 1);     // multiple of 16
     const int grid = nitems < MAX_WGS ? nitems & ~7 : MAX_WGS;
+    if (a.in_scale || a.res_scale) {                  // a folded channel attention (persistent kernel, three terms only)
+        if ((a.in_scale && a.res_scale) || a.terms != 3 || nitems < kSmallItems || HW != kLR || SHUFFLE || POOL) return hipErrorInvalidValue;
+        if constexpr (HW == kLR && !SHUFFLE && !POOL) {
+            if (a.in_scale)
+                hipLaunchKernelGGL((conv3x3_f32s_kernel<HW, false, false, RES, 0, 3, 1>), dim3((unsigned)grid), dim3(256), LDS_BYTES, s, a, nitems);
+            else if (RES)
+                hipLaunchKernelGGL((conv3x3_f32s_kernel<HW, false, false, RES, 0, 3, 2>), dim3((unsigned)grid), dim3(256), LDS_BYTES, s, a, nitems);
+            else
+                return hipErrorInvalidValue;
+            return hipGetLastError();
+        }
+        return hipErrorInvalidValue;
+    }
     if (a.terms == 3 && nitems < kSmallItems) return launch_small<HW, SHUFFLE, POOL, RES>(a, nitems, s);
     if (a.terms == 1) {
         if (POOL) return hipErrorInvalidValue;        // the f16-product variant serves the training operators only

@@ -54,10 +54,10 @@ struct Conv3x3Args {
                                       // by its own (eval forward: an image's result does not depend on its batch)
     int terms = 3;                    // split kernel only: 3 = hi*hi + hi*lo + lo*hi (fp32 products), 1 = hi*hi alone (f16
                                       // products, fp32 accumulation: the mixed-precision training convs)
-    const float* in_scale = nullptr;  // bf16 kernel only (eval forward): [N][96] channel-attention scales the INPUT is multiplied
+    const float* in_scale = nullptr;  // bf16 and split kernels (eval forward): [N][96] channel-attention scales the INPUT is multiplied
                                       // by while its halo tile is staged (products rounded to bf16: what the attention's
                                       // in-place pass used to store), so that pass over the tensor is not run
-    const float* res_scale = nullptr; // bf16 kernel only: the same for the RESIDUAL (the block behind an attention reads the
+    const float* res_scale = nullptr; // the same for the RESIDUAL (the block behind an attention reads the
                                       // unscaled tensor twice: as conv1's input and as conv2's residual)
     const float* in_amax = nullptr;   // split kernel only: kAmaxSlots device floats whose maximum is >= max |in| (any
                                       // bound within a few binades): the input is scaled by a power of two into f16's
@@ -175,7 +175,7 @@ struct ChanAttnArgs {
     float* scale_out;      // [N][96]
     int N;
     int hw;                // pixels per image (4096)
-    int scale_only = 0;    // bf16 kernel: 1 = compute scale_out and leave x alone (the convs behind apply it: Conv3x3Args::in_scale)
+    int scale_only = 0;    // 1 = compute scale_out (and refresh amax) and leave x alone (the convs behind apply it: Conv3x3Args::in_scale)
     float* amax = nullptr; // split path, eval forward (fp32 kernel only): [N] per-image bounds of max |x| left by the conv
                            // in front; multiplied by the image's largest channel scale, so the conv behind scales by a
                            // bound of what it really reads (a strongly damping attention would leave the old one far too high)

@@ -146,7 +146,8 @@ __device__ __forceinline__ void ca_fc(const ChanAttnArgs& a, int n, float* s_poo
 __global__ __launch_bounds__(256) void chan_attn_f32_kernel(ChanAttnArgs a)
 {
     __shared__ float s_pool[kC], s_hid[12], s_scale[kC];
-    const int n = blockIdx.x / CA_SLICES, slice = blockIdx.x % CA_SLICES;
+    const int nsl = a.scale_only ? 1 : CA_SLICES;
+    const int n = blockIdx.x / nsl, slice = blockIdx.x % nsl;
     ca_fc<float>(a, n, s_pool, s_hid, s_scale);
     if (slice == 0 && threadIdx.x < kC) a.scale_out[(size_t)n * kC + threadIdx.x] = s_scale[threadIdx.x];
     if (a.amax && slice == 0 && threadIdx.x < 64) {            // |x * s| <= amax * max_c s: the refreshed per-image bound
@@ -156,6 +157,7 @@ __global__ __launch_bounds__(256) void chan_attn_f32_kernel(ChanAttnArgs a)
         for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
         if (lane == 0) a.amax[n] *= m;
     }
+    if (a.scale_only) return;                                 // (the convs behind apply the scales: Conv3x3Args::in_scale)
     const int per_slice = a.hw * kC / 4 / CA_SLICES;          // float4 per slice
     f32x4* x = (f32x4*)a.x + (size_t)n * a.hw * kC / 4 + (size_t)slice * per_slice;
     for (int i = threadIdx.x; i < per_slice; i += 256) {
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(256) void chan_attn_f32_kernel(ChanAttnArgs a)
 hipError_t launch_chan_attn_f32(const ChanAttnArgs& a, hipStream_t s)
 {
     if ((a.hw * kC / 4) % CA_SLICES) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(chan_attn_f32_kernel, dim3((unsigned)(a.N * CA_SLICES)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(chan_attn_f32_kernel, dim3((unsigned)(a.N * (a.scale_only ? 1 : CA_SLICES))), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

@@ -540,18 +540,25 @@ def test_train_mode_forward_under_bf16_autocast():
     assert yb2.dtype == torch.bfloat16
 
 
-@pytest.mark.parametrize("n", [1, 5, 19])
-def test_bf16_forward_with_the_channel_attention_folded_into_the_convs_is_bit_identical(gen, n, monkeypatch):
-    """bf16 eval forward (Generator.py:15-27,76-78): by default the two channel attentions only compute their scales and the
-    convs behind them multiply where they read (conv1's input tile when it is staged, conv2's residual in the epilogue, the
-    mid conv's input), rounding each product to bf16 as the attention's in-place pass did.  SRGEN_CA_FOLD=0 runs that pass:
-    the outputs must be equal bit for bit.  Distinct random images, batches that end inside a workgroup's item range."""
+@pytest.mark.parametrize("dtype,n", [(torch.bfloat16, 1), (torch.bfloat16, 5), (torch.bfloat16, 19), (torch.float32, 5),
+                                     (torch.float32, 6), (torch.float32, 19)])
+def test_forward_with_the_channel_attention_folded_into_the_convs_is_bit_identical(gen, dtype, n, monkeypatch):
+    """Eval forward (Generator.py:15-27,76-78), bf16 and fp32 (split path, 6 images or more: the persistent kernel): by
+    default the two channel attentions only compute their scales and the convs behind them multiply where they read (conv1's
+    input tile when it is staged, conv2's residual in the epilogue, the mid conv's input), each product rounded to the
+    tensor's type as the attention's in-place pass did.  SRGEN_CA_FOLD=0 runs that pass: the outputs must be equal bit for
+    bit.  Distinct random images (one of them scaled by 1e-3, one by 50: the per-image range scaling of the split path),
+    batches that end inside a workgroup's item range."""
     g = torch.Generator().manual_seed(123 + n)
-    x = torch.rand((n, 3, 64, 64), generator=g).cuda().to(torch.bfloat16)
+    x = torch.rand((n, 3, 64, 64), generator=g)
+    x[0] *= 1e-3
+    if n > 1:
+        x[n - 1] *= 50.0
+    x = x.cuda().to(dtype)
     with torch.no_grad():
         y = gen(x)
         monkeypatch.setenv("SRGEN_CA_FOLD", "0")
         y0 = gen(x)
     torch.cuda.synchronize()
-    assert y.dtype == torch.bfloat16 and float(y.float().abs().max()) > 0
+    assert y.dtype == dtype and float(y.float().abs().max()) > 0
     assert torch.equal(y, y0)
