@@ -7,7 +7,7 @@
 // :36,:9,:70 and the residual adds :42,:78 are the epilogue.
 //
 // Structure (one workgroup = 4 waves = 4 rows x 64 pixels x 96 output channels; persistent, two
-// workgroups per CU, de-phased at start so one's prologue / epilogue is covered by the other's MFMAs):
+// workgroups per CU, so one's prologue / epilogue is covered by the other's MFMAs -- they drift apart by themselves):
 //   * GEMM view: M = 96 co (the MFMA A operand: weights), N = pixels (B operand), K = 9 taps x 96 ci,
 //     walked as 2 ci-chunks x 9 taps x 3 k16-steps = 54 steps of 6 MFMAs per wave; the accumulator
 //     then holds 4 consecutive channels of one pixel in 4 consecutive registers;
@@ -302,13 +302,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(Conv3x3Args a, int
     float* const ldsRS = (float*)(lds + RS_OFF);
     int rsb = 0;                                  // buffer of the current item's residual scales
     if (SC == 2 && tid < kC) ldsRS[tid] = a.res_scale[(size_t)cur.n * kC + tid];
-    // De-phase the two workgroups that share a CU (the first half of the grid is dealt one per
-    // CU before the second half doubles up): while one is in its epilogue / staging the other
-    // has the matrix pipe to itself.  Speed only.
-    if ((int)blockIdx.x >= ((int)gridDim.x >> 1) && gridDim.x >= 2 * 256) {
-#pragma unroll 1
-        for (int i = 0; i < 2; ++i) __builtin_amdgcn_s_sleep(100);
-    }
+    // (Rounds 1-2 de-phased the two workgroups that share a CU here -- the second half of the grid slept ~6 us -- so that one's
+    // epilogue ran beside the other's MFMAs.  Measured again at the end of round 3: without the sleep the batch-256 forward
+    // runs 7.85 instead of 7.97 ms and the 64-image 16-bit training step 10.65 instead of 10.85 ms: the workgroups drift apart
+    // by themselves within the first item, the sleep only delayed the launch's end.)
     store_a();
     wait_vm0();                                   // slabs 0, 1 (asm copies: not known to the compiler)
     __syncthreads();
